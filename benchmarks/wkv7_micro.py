@@ -1,0 +1,97 @@
+"""WKV7 kernel micro-benchmark: per-launch time (HIP events on the launch stream), algorithmic
+bytes (fwd 34 B, bwd 46 B per bf16 element at chunk length 16) and achieved GB/s.
+
+    python benchmarks/wkv7_micro.py [--B 8] [--T 2624] [--H 32] [--iters 20]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FWD_BYTES_PER_ELEM = 18 + 256 // 16    # 6 bf16 in + y + sa(f32) + s checkpoint  = 34
+BWD_BYTES_PER_ELEM = 30 + 256 // 16    # 7 bf16 in + sa + s + 6 bf16 grads       = 46
+HBM_PEAK_GBPS = 8000.0                 # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def synth_inputs(B, T, H, device, seed=42):
+    """Inputs with the structure RWKV_Tmix_x070 feeds the op (src/model.py:175-190), made on device."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    shp = (B, T, H, 64)
+    rn = lambda: torch.randn(shp, device=device, generator=g)
+    q, k, v = rn() * 0.5, rn() * 0.5, rn() * 0.5
+    w = -torch.nn.functional.softplus(-rn()) - 0.5
+    kk = torch.nn.functional.normalize(rn(), dim=-1, p=2.0)
+    gate = torch.sigmoid(rn())
+    dy = rn()
+    return [x.bfloat16().contiguous() for x in (w, q, k, v, -kk, kk * gate, dy)]
+
+
+def time_wkv7(B, T, H, iters=20, warmup=3, device="cuda:0", variant=-1):
+    from visualrwkv_amd import hip_lib
+    lib = hip_lib.load()
+    w, q, k, v, z, a, dy = synth_inputs(B, T, H, device)
+    y = torch.empty_like(v)
+    s = torch.empty(B, H, T // 16, 64, 64, dtype=torch.float32, device=device)
+    sa = torch.empty(B, T, H, 64, dtype=torch.float32, device=device)
+    grads = [torch.empty_like(w) for _ in range(6)]
+    st = torch.cuda.current_stream().cuda_stream
+    lib.vrwkv_wkv7_set_forward_variant(variant)
+
+    def fwd():
+        rc = lib.vrwkv_wkv7_forward_bf16(B, T, H, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), z.data_ptr(),
+                                         a.data_ptr(), y.data_ptr(), s.data_ptr(), sa.data_ptr(), st)
+        assert rc == 0, rc
+
+    def bwd():
+        rc = lib.vrwkv_wkv7_backward_bf16(B, T, H, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), z.data_ptr(),
+                                          a.data_ptr(), dy.data_ptr(), s.data_ptr(), sa.data_ptr(),
+                                          *[g.data_ptr() for g in grads], st)
+        assert rc == 0, rc
+
+    def timeit(fn):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    fwd_ms, bwd_ms = timeit(fwd), timeit(bwd)
+    lib.vrwkv_wkv7_set_forward_variant(-1)
+    elems = B * T * H * 64
+    res = {
+        "B": B, "T": T, "H": H, "elems": elems,
+        "fwd_ms": fwd_ms, "bwd_ms": bwd_ms,
+        "fwd_GBps": elems * FWD_BYTES_PER_ELEM / fwd_ms / 1e6,
+        "bwd_GBps": elems * BWD_BYTES_PER_ELEM / bwd_ms / 1e6,
+    }
+    res["fwd_frac"] = res["fwd_GBps"] / HBM_PEAK_GBPS
+    res["bwd_frac"] = res["bwd_GBps"] / HBM_PEAK_GBPS
+    return res
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, nargs="+", default=[8])
+    ap.add_argument("--T", type=int, default=2624)
+    ap.add_argument("--H", type=int, default=32)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--variants", type=int, nargs="+", default=[-1])
+    args = ap.parse_args()
+    for B in args.B:
+        for var in args.variants:
+            r = time_wkv7(B, args.T, args.H, iters=args.iters, variant=var)
+            r["variant"] = var
+            print(json.dumps(r))

@@ -1,0 +1,65 @@
+/* C-ABI of libvisualrwkv_hip.so -- the MI355X (gfx950) drop-in for the native WKV7 operator of
+ * howard-hou/VisualRWKV (v7.xx).
+ *
+ * Every entry point takes plain device pointers, sizes and a HIP stream (as void*, NULL = the
+ * legacy default stream) and returns 0 on success, a positive hipError_t value when the HIP
+ * runtime reported an error, or a negative VRWKV_E* code for bad arguments.  No torch types, no
+ * allocation, no retained state: the caller owns every buffer (as in the reference, where
+ * WindBackstepping allocates y/s/sa and the six gradients, src/model.py:52-54,63).
+ *
+ * Reference interface each function replaces (paths relative to VisualRWKV-v7/v7.00/):
+ *   vrwkv_wkv7_forward_bf16   <- cuda_forward(B,T,H,w,q,k,v,z,a,y,s,sa)        cuda/wkv7_op.cpp:5, cuda/wkv7_cuda.cu:132-134
+ *   vrwkv_wkv7_backward_bf16  <- cuda_backward(B,T,H,w,q,k,v,z,a,dy,s,sa,d*)   cuda/wkv7_op.cpp:12, cuda/wkv7_cuda.cu:135-138
+ * which sit under torch.ops.wind_backstepping.{forward,backward} (cuda/wkv7_op.cpp:21-29).
+ *
+ * Layouts: activations (B,T,H,64) contiguous bf16; `s` (B,H,T/16,64,64) f32 holding
+ * S^T at the end of every 16-token chunk (s[b,h,c,j,i] = S[i][j]); `sa` (B,T,H,64) f32.
+ * T must be a multiple of 16; the head size is 64.  Argument names follow the op schema:
+ * z = the kernel's `a` (= -kk), a = the kernel's `b` (= kk * gate).
+ */
+#ifndef VISUALRWKV_HIP_H
+#define VISUALRWKV_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VRWKV_OK 0
+#define VRWKV_EINVAL (-1)   /* null pointer, non-positive size                     */
+#define VRWKV_ESHAPE (-2)   /* T % 16 != 0                                         */
+#define VRWKV_EALIGN (-3)   /* a pointer is not 16-byte aligned                    */
+
+#define VRWKV_HEAD_SIZE 64
+#define VRWKV_CHUNK_LEN 16
+
+/* ABI version of this header; bumped on any signature change. */
+int vrwkv_abi_version(void);
+
+/* Human-readable text for a return code of this library (static storage). */
+const char* vrwkv_strerror(int code);
+
+int vrwkv_wkv7_forward_bf16(int B, int T, int H,
+                            const void* w, const void* q, const void* k, const void* v,
+                            const void* z, const void* a,
+                            void* y, float* s, float* sa, void* stream);
+
+int vrwkv_wkv7_backward_bf16(int B, int T, int H,
+                             const void* w, const void* q, const void* k, const void* v,
+                             const void* z, const void* a, const void* dy,
+                             const float* s, const float* sa,
+                             void* dw, void* dq, void* dk, void* dv, void* dz, void* da,
+                             void* stream);
+
+/* Launch-shape override for benchmarking/tests: variant < 0 restores the automatic choice.
+ * forward variants: 0 = 1 wave/head (4x16 lane tiles), 1 = 2 waves/head, 2 = 4 waves/head. */
+int vrwkv_wkv7_set_forward_variant(int variant);
+
+/* Hardware probe for the GPU tests (MFMA lane maps, cross-lane primitives); one wave.
+ * which: 0 = 16x16x4 f32, 1 = 32x32x2 f32, 2 = 16x16x32 bf16, 3 = 32x32x16 bf16 (d = a*b, row-major
+ * f32 operands), 4 = cross-lane primitives (a: 64 floats, d: 384 floats). */
+int vrwkv_debug_probe(int which, const float* a, const float* b, float* d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

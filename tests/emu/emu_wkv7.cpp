@@ -1,0 +1,29 @@
+// Runs the WKV7 device kernels (visualrwkv_amd/csrc/wkv7_kernels.h) under the host lockstep
+// emulator.  TEST INFRASTRUCTURE ONLY -- built by tests/emu/build.py into tests/emu/libemu_kernels.so.
+#include <gfx950_prims.h>   // resolves to tests/emu/gfx950_prims.h (-I order)
+#include <wkv7_kernels.h>
+
+extern "C" {
+
+int emu_wkv7_forward(int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
+                     const void* z, const void* a, void* y, float* s, float* sa, int variant) {
+    wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
+                    (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, s, sa};
+    dim3 grid((unsigned)(B * H));
+    if (variant == 0) emu::launch(grid, dim3(64), [&] { wkv7::fwd_kernel<16, 8>(p); });
+    else if (variant == 1) emu::launch(grid, dim3(128), [&] { wkv7::fwd_kernel<8, 16>(p); });
+    else emu::launch(grid, dim3(256), [&] { wkv7::fwd_kernel<4, 16>(p); });
+    return 0;
+}
+
+int emu_wkv7_backward(int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
+                      const void* z, const void* a, const void* dy, const float* s, const float* sa,
+                      void* dw, void* dq, void* dk, void* dv, void* dz, void* da) {
+    wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
+                    (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
+                    (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
+    emu::launch(dim3((unsigned)(B * H)), dim3(256), [&] { wkv7::bwd_kernel<8>(p); });
+    return 0;
+}
+
+}  // extern "C"

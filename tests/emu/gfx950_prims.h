@@ -1,0 +1,136 @@
+// Host model of visualrwkv_amd/csrc/gfx950_prims.h (same interface).  TEST INFRASTRUCTURE ONLY.
+// Implements the wave64 cross-lane and MFMA semantics the kernels rely on, on top of hip_emu.h.
+// The MFMA lane->element maps here are the ones documented in the device header; the GPU test
+// tests/test_mfma_layout.py checks the hardware against the same maps.
+#pragma once
+#include "hip_emu.h"
+
+#define DEVFN static inline
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+DEVFN float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
+DEVFN float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+DEVFN float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+DEVFN uint32_t f32_to_bf16_bits(float x) {
+    uint32_t u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+DEVFN uint32_t pack_bf16x2(float lo, float hi) { return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16); }
+
+DEVFN float fast_exp(float x) { return expf(x); }
+DEVFN float fast_rcp(float x) { return 1.0f / x; }
+DEVFN float fast_log(float x) { return logf(x); }
+DEVFN float fast_tanh(float x) { return tanhf(x); }
+DEVFN float fast_rsqrt(float x) { return 1.0f / sqrtf(x); }
+
+DEVFN int lane_id() { return emu::flat_tid() & 63; }
+
+// value of `x` held by lane `src` of the calling lane's wave (all lanes must call)
+DEVFN uint32_t emu_wave_read(uint32_t x, int src) {
+    emu::slot(emu::flat_tid())[0] = x;
+    emu::wave_barrier();
+    uint32_t r = (uint32_t)emu::slot(emu::wave_base() + (src & 63))[0];
+    emu::wave_barrier();
+    return r;
+}
+DEVFN float lane_xor(float x, int mask) { return __uint_as_float(emu_wave_read(__float_as_uint(x), lane_id() ^ mask)); }
+DEVFN float lane_bcast(float x, int src) { return __uint_as_float(emu_wave_read(__float_as_uint(x), src)); }
+DEVFN float lane_xor1(float x) { return lane_xor(x, 1); }
+DEVFN float lane_xor2(float x) { return lane_xor(x, 2); }
+DEVFN float lane_half_mirror(float x) { int l = lane_id(); return __uint_as_float(emu_wave_read(__float_as_uint(x), (l & ~7) | (7 - (l & 7)))); }
+DEVFN float lane_mirror(float x) { int l = lane_id(); return __uint_as_float(emu_wave_read(__float_as_uint(x), (l & ~15) | (15 - (l & 15)))); }
+
+template <int LOG2> DEVFN float group_sum(float x) {
+    if (LOG2 >= 1) x += lane_xor1(x);
+    if (LOG2 >= 2) x += lane_xor2(x);
+    if (LOG2 >= 3) x += lane_half_mirror(x);
+    if (LOG2 >= 4) x += lane_mirror(x);
+    if (LOG2 >= 5) x += lane_xor(x, 16);
+    if (LOG2 >= 6) x += lane_xor(x, 32);
+    return x;
+}
+
+// ---- MFMA models: k-ordered fmaf chains (bitwise what the f32 MFMA does; bf16 products are exact in f32)
+DEVFN f32x4 mfma_16x16x4_f32(float a, float b, f32x4 c) {
+    int me = emu::flat_tid(), wb = emu::wave_base(), l = me & 63;
+    float* s = (float*)emu::slot(me); s[0] = a; s[1] = b;
+    emu::wave_barrier();
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) * 4 + r, col = l & 15;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            float av = ((float*)emu::slot(wb + k * 16 + row))[0];
+            float bv = ((float*)emu::slot(wb + k * 16 + col))[1];
+            acc = fmaf(av, bv, acc);
+        }
+        d[r] = acc;
+    }
+    emu::wave_barrier();
+    return d;
+}
+DEVFN f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
+    int me = emu::flat_tid(), wb = emu::wave_base(), l = me & 63;
+    float* s = (float*)emu::slot(me); s[0] = a; s[1] = b;
+    emu::wave_barrier();
+    f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) {
+            float av = ((float*)emu::slot(wb + k * 32 + row))[0];
+            float bv = ((float*)emu::slot(wb + k * 32 + col))[1];
+            acc = fmaf(av, bv, acc);
+        }
+        d[r] = acc;
+    }
+    emu::wave_barrier();
+    return d;
+}
+DEVFN f32x4 mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    int me = emu::flat_tid(), wb = emu::wave_base(), l = me & 63;
+    short* s = (short*)emu::slot(me);
+    for (int e = 0; e < 8; ++e) { s[e] = a[e]; s[8 + e] = b[e]; }
+    emu::wave_barrier();
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) * 4 + r, col = l & 15;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) {
+            short av = ((short*)emu::slot(wb + (k >> 3) * 16 + row))[k & 7];
+            short bv = ((short*)emu::slot(wb + (k >> 3) * 16 + col))[8 + (k & 7)];
+            acc += bf16_to_f32((uint16_t)av) * bf16_to_f32((uint16_t)bv);
+        }
+        d[r] = acc;
+    }
+    emu::wave_barrier();
+    return d;
+}
+DEVFN f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    int me = emu::flat_tid(), wb = emu::wave_base(), l = me & 63;
+    short* s = (short*)emu::slot(me);
+    for (int e = 0; e < 8; ++e) { s[e] = a[e]; s[8 + e] = b[e]; }
+    emu::wave_barrier();
+    f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            short av = ((short*)emu::slot(wb + (k >> 3) * 32 + row))[k & 7];
+            short bv = ((short*)emu::slot(wb + (k >> 3) * 32 + col))[8 + (k & 7)];
+            acc += bf16_to_f32((uint16_t)av) * bf16_to_f32((uint16_t)bv);
+        }
+        d[r] = acc;
+    }
+    emu::wave_barrier();
+    return d;
+}
+
+DEVFN void block_sync() { emu::block_barrier(); }
+DEVFN void wave_lds_fence() { emu::wave_barrier(); }

@@ -1,0 +1,63 @@
+"""The C-ABI shared library: loads here (no GPU) and exports exactly what include/*.h declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "visualrwkv_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(vrwkv_\w+)\s*\(", txt)))
+
+
+def test_header_symbols_exported(hip_lib):
+    names = _declared()
+    assert "vrwkv_wkv7_forward_bf16" in names and "vrwkv_wkv7_backward_bf16" in names
+    for n in names:
+        assert hasattr(hip_lib, n), f"{n} declared in include/visualrwkv_hip.h but not exported"
+
+
+def test_python_prototypes_cover_header():
+    from visualrwkv_amd import hip_lib as hl
+    assert sorted(hl.PROTOTYPES) == _declared()
+
+
+def test_argument_validation_without_gpu(hip_lib):
+    """Argument errors are reported before any HIP call, so they can be checked on a CPU box."""
+    assert hip_lib.vrwkv_abi_version() == 1
+    null = ctypes.c_void_p(0)
+    buf = (ctypes.c_char * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    args = [p] * 10
+    assert hip_lib.vrwkv_wkv7_forward_bf16(1, 15, 1, *args) == -2          # T % 16
+    assert hip_lib.vrwkv_wkv7_forward_bf16(0, 16, 1, *args) == -1          # B <= 0
+    assert hip_lib.vrwkv_wkv7_forward_bf16(1, 16, 1, null, *args[1:]) == -1
+    mis = ctypes.c_void_p(p.value + 2)
+    if p.value % 16 == 0:
+        assert hip_lib.vrwkv_wkv7_forward_bf16(1, 16, 1, mis, *args[1:]) == -3
+    assert b"multiple of 16" in hip_lib.vrwkv_strerror(-2)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from visualrwkv_amd import hip_lib as hl
+    monkeypatch.setattr(hl, "_lib", None)
+    monkeypatch.setattr(hl, "LIB_PATH", str(tmp_path / "nope.so"))
+    try:
+        hl.load()
+    except hl.HipLibraryError as e:
+        assert "no CPU or PyTorch fallback" in str(e)
+    else:
+        raise AssertionError("expected HipLibraryError")
+
+
+def test_op_rejects_cpu_tensors():
+    import pytest
+    import torch
+    import visualrwkv_amd.wkv7 as wk
+    x = torch.zeros(1, 16, 1, 64, dtype=torch.bfloat16)
+    s = torch.zeros(1, 1, 1, 64, 64)
+    sa = torch.zeros(1, 16, 1, 64)
+    with pytest.raises(NotImplementedError):
+        torch.ops.wind_backstepping.forward(x, x, x, x, x, x, x.clone(), s, sa)

@@ -1,0 +1,39 @@
+"""Hardware check of the MFMA lane->element maps and cross-lane primitives that
+visualrwkv_amd/csrc/gfx950_prims.h documents and tests/emu/gfx950_prims.h models."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _probe(lib, which, a, b, dshape):
+    d = torch.zeros(dshape, device="cuda")
+    rc = lib.vrwkv_debug_probe(which, a.data_ptr(), b.data_ptr() if b is not None else 0, d.data_ptr(),
+                               torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    return d
+
+
+@pytest.mark.parametrize("which,M,N,K,bf", [(0, 16, 16, 4, False), (1, 32, 32, 2, False), (2, 16, 16, 32, True), (3, 32, 32, 16, True)])
+def test_mfma_maps(hip_lib, which, M, N, K, bf):
+    g = torch.Generator().manual_seed(which)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(K, N, generator=g)          # asymmetric operands: a transposed map cannot pass
+    if bf:
+        a, b = a.bfloat16().float(), b.bfloat16().float()
+    d = _probe(hip_lib, which, a.cuda(), b.cuda(), (M, N)).cpu()
+    ref = a.double() @ b.double()
+    assert torch.allclose(d.double(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_lane_primitives(hip_lib):
+    x = torch.arange(64, dtype=torch.float32) * 1.5 + 1
+    d = _probe(hip_lib, 4, x.cuda(), None, (384,)).cpu().view(6, 64)
+    lanes = torch.arange(64)
+    assert torch.equal(d[0], x.view(4, 16).sum(1, keepdim=True).expand(4, 16).reshape(64))
+    assert torch.equal(d[1], x[(lanes & ~7) | (7 - (lanes & 7))])
+    assert torch.equal(d[2], x[(lanes & ~15) | (15 - (lanes & 15))])
+    assert torch.equal(d[3], x[lanes ^ 16])
+    assert torch.equal(d[4], x[lanes ^ 32])
+    assert torch.allclose(d[5], x.sum().expand(64))

@@ -1,0 +1,82 @@
+// gfx950 (CDNA4 / MI355X) device primitives used by the kernels in this directory.
+//
+// Everything here is wave64-specific.  The kernels only ever call these wrappers (never the
+// raw builtins), which keeps the lane/fragment conventions in one place; tests/emu/ holds a
+// host-side model of the SAME interface (test infrastructure) that the CPU test-suite uses to
+// run the kernels' index math in lockstep without a GPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DEVFN __device__ __forceinline__
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------- bf16 <-> fp32
+DEVFN float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }          // element 0 of a packed pair
+DEVFN float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }  // element 1
+DEVFN float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even, NaN preserved (same result as __float2bfloat16_rn)
+DEVFN uint32_t f32_to_bf16_bits(float x) {
+    uint32_t u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+DEVFN uint32_t pack_bf16x2(float lo, float hi) { return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16); }
+
+// ---------------------------------------------------------------- math
+DEVFN float fast_exp(float x) { return __expf(x); }          // v_exp_f32 path
+DEVFN float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+DEVFN float fast_log(float x) { return __logf(x); }
+DEVFN float fast_tanh(float x) { return tanhf(x); }
+DEVFN float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+
+// ---------------------------------------------------------------- cross-lane (wave64)
+// DPP within rows of 16 lanes.  Controls: quad_perm 0x00-0xff, row_shr 0x110+n, row_ror 0x120+n,
+// row_mirror 0x140, row_half_mirror 0x141.
+template <int CTRL> DEVFN float dpp_mov(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+DEVFN float lane_xor1(float x) { return dpp_mov<0xB1>(x); }        // quad_perm [1,0,3,2]
+DEVFN float lane_xor2(float x) { return dpp_mov<0x4E>(x); }        // quad_perm [2,3,0,1]
+DEVFN float lane_half_mirror(float x) { return dpp_mov<0x141>(x); }  // i <-> 7-i   inside each 8 lanes
+DEVFN float lane_mirror(float x) { return dpp_mov<0x140>(x); }       // i <-> 15-i  inside each 16 lanes
+// arbitrary xor partner (ds_bpermute / permlane paths, chosen by the compiler)
+DEVFN float lane_xor(float x, int mask) { return __shfl_xor(x, mask, 64); }
+DEVFN float lane_bcast(float x, int src_lane) { return __shfl(x, src_lane, 64); }
+DEVFN int lane_id() { return (int)(threadIdx.x & 63); }
+
+// Sum over the 2^LOG2 lanes that share the high lane bits (all-reduce: every lane gets the sum).
+template <int LOG2> DEVFN float group_sum(float x) {
+    if (LOG2 >= 1) x += lane_xor1(x);
+    if (LOG2 >= 2) x += lane_xor2(x);
+    if (LOG2 >= 3) x += lane_half_mirror(x);
+    if (LOG2 >= 4) x += lane_mirror(x);
+    if (LOG2 >= 5) x += lane_xor(x, 16);
+    if (LOG2 >= 6) x += lane_xor(x, 32);
+    return x;
+}
+
+// ---------------------------------------------------------------- MFMA (fragment maps: see DESIGN.md)
+// 16x16x4 f32:  A: lane l holds A[i=l&15][k=l>>4];  B: lane l holds B[k=l>>4][j=l&15];
+//               C/D reg r: row = (l>>4)*4 + r, col = l&15.
+DEVFN f32x4 mfma_16x16x4_f32(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// 32x32x2 f32:  A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; C/D reg r: row=(r&3)+8*(r>>2)+4*(l>>5), col=l&31
+DEVFN f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+// 16x16x32 bf16: A[i=l&15][k=(l>>4)*8+e], B[k=(l>>4)*8+e][j=l&15], e=0..7; C/D as 16x16x4.
+DEVFN f32x4 mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// 32x32x16 bf16: A[i=l&31][k=(l>>5)*8+e], B[k=(l>>5)*8+e][j=l&31]; C/D as 32x32x2.
+DEVFN f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+// ---------------------------------------------------------------- sync
+DEVFN void block_sync() { __syncthreads(); }
+// LDS ops of one wave execute in order; this only stops the compiler from moving LDS accesses
+// across the point where lanes exchange data through LDS.
+DEVFN void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}

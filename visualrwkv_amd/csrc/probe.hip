@@ -1,0 +1,76 @@
+// Hardware probes used by the GPU tests: check the MFMA lane->element maps documented in
+// gfx950_prims.h (and modelled by tests/emu/gfx950_prims.h) on the real chip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/visualrwkv_hip.h"
+#include <gfx950_prims.h>
+
+namespace {
+
+// D[M][N] = A[M][K] * B[K][N], one wave, operands row-major f32 in global memory.
+__global__ void probe_16x16x4_f32(const float* A, const float* B, float* D) {
+    const int l = threadIdx.x;
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    c = mfma_16x16x4_f32(A[(l & 15) * 4 + (l >> 4)], B[(l >> 4) * 16 + (l & 15)], c);
+    for (int r = 0; r < 4; ++r) D[((l >> 4) * 4 + r) * 16 + (l & 15)] = c[r];
+}
+__global__ void probe_32x32x2_f32(const float* A, const float* B, float* D) {
+    const int l = threadIdx.x;
+    f32x16 c;
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    c = mfma_32x32x2_f32(A[(l & 31) * 2 + (l >> 5)], B[(l >> 5) * 32 + (l & 31)], c);
+    for (int r = 0; r < 16; ++r) D[((r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * 32 + (l & 31)] = c[r];
+}
+__global__ void probe_16x16x32_bf16(const float* A, const float* B, float* D) {
+    const int l = threadIdx.x;
+    bf16x8 a, b;
+    for (int e = 0; e < 8; ++e) {
+        const int k = (l >> 4) * 8 + e;
+        a[e] = (short)f32_to_bf16_bits(A[(l & 15) * 32 + k]);
+        b[e] = (short)f32_to_bf16_bits(B[k * 16 + (l & 15)]);
+    }
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    c = mfma_16x16x32_bf16(a, b, c);
+    for (int r = 0; r < 4; ++r) D[((l >> 4) * 4 + r) * 16 + (l & 15)] = c[r];
+}
+__global__ void probe_32x32x16_bf16(const float* A, const float* B, float* D) {
+    const int l = threadIdx.x;
+    bf16x8 a, b;
+    for (int e = 0; e < 8; ++e) {
+        const int k = (l >> 5) * 8 + e;
+        a[e] = (short)f32_to_bf16_bits(A[(l & 31) * 16 + k]);
+        b[e] = (short)f32_to_bf16_bits(B[k * 32 + (l & 31)]);
+    }
+    f32x16 c;
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    c = mfma_32x32x16_bf16(a, b, c);
+    for (int r = 0; r < 16; ++r) D[((r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * 32 + (l & 31)] = c[r];
+}
+// cross-lane primitives: out[0..63] = group_sum<4>(in), out[64..] = half_mirror, mirror, xor16, xor32
+__global__ void probe_lanes(const float* in, float* out) {
+    const int l = threadIdx.x;
+    const float x = in[l];
+    out[l] = group_sum<4>(x);
+    out[64 + l] = lane_half_mirror(x);
+    out[128 + l] = lane_mirror(x);
+    out[192 + l] = lane_xor(x, 16);
+    out[256 + l] = lane_xor(x, 32);
+    out[320 + l] = group_sum<6>(x);
+}
+
+}  // namespace
+
+extern "C" int vrwkv_debug_probe(int which, const float* a, const float* b, float* d, void* stream) {
+    if (!a || !d) return VRWKV_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    switch (which) {
+        case 0: hipLaunchKernelGGL(probe_16x16x4_f32, dim3(1), dim3(64), 0, st, a, b, d); break;
+        case 1: hipLaunchKernelGGL(probe_32x32x2_f32, dim3(1), dim3(64), 0, st, a, b, d); break;
+        case 2: hipLaunchKernelGGL(probe_16x16x32_bf16, dim3(1), dim3(64), 0, st, a, b, d); break;
+        case 3: hipLaunchKernelGGL(probe_32x32x16_bf16, dim3(1), dim3(64), 0, st, a, b, d); break;
+        case 4: hipLaunchKernelGGL(probe_lanes, dim3(1), dim3(64), 0, st, a, d); break;
+        default: return VRWKV_EINVAL;
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? VRWKV_OK : (int)e;
+}

@@ -1,0 +1,86 @@
+// Host launchers + C-ABI for the WKV7 kernels (include/visualrwkv_hip.h).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/visualrwkv_hip.h"
+#include <wkv7_kernels.h>
+
+namespace {
+
+int g_fwd_variant = -1;
+
+inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+
+int check_common(int B, int T, int H) {
+    if (B <= 0 || T <= 0 || H <= 0) return VRWKV_EINVAL;
+    if (T % VRWKV_CHUNK_LEN != 0) return VRWKV_ESHAPE;   // cuda_backward asserts this, wkv7_cuda.cu:136
+    return VRWKV_OK;
+}
+
+int finish_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? VRWKV_OK : (int)e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vrwkv_abi_version(void) { return 1; }
+
+const char* vrwkv_strerror(int code) {
+    switch (code) {
+        case VRWKV_OK: return "ok";
+        case VRWKV_EINVAL: return "invalid argument (null pointer or non-positive size)";
+        case VRWKV_ESHAPE: return "T must be a multiple of 16";
+        case VRWKV_EALIGN: return "pointer not 16-byte aligned";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+int vrwkv_wkv7_set_forward_variant(int variant) {
+    if (variant > 2) return VRWKV_EINVAL;
+    g_fwd_variant = variant;
+    return VRWKV_OK;
+}
+
+int vrwkv_wkv7_forward_bf16(int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
+                            const void* z, const void* a, void* y, float* s, float* sa, void* stream) {
+    int rc = check_common(B, T, H);
+    if (rc) return rc;
+    if (!w || !q || !k || !v || !z || !a || !y || !s || !sa) return VRWKV_EINVAL;
+    if (misaligned(w) || misaligned(q) || misaligned(k) || misaligned(v) || misaligned(z) || misaligned(a) ||
+        misaligned(y) || misaligned(s) || misaligned(sa))
+        return VRWKV_EALIGN;
+    wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
+                    (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, s, sa};
+    hipStream_t st = (hipStream_t)stream;
+    const long heads = (long)B * H;
+    int variant = g_fwd_variant;
+    if (variant < 0) variant = heads >= 1024 ? 0 : heads >= 512 ? 1 : 2;   // >= 1024 waves when possible
+    const dim3 grid((unsigned)heads);
+    if (variant == 0) hipLaunchKernelGGL((wkv7::fwd_kernel<16, 8>), grid, dim3(64), 0, st, p);
+    else if (variant == 1) hipLaunchKernelGGL((wkv7::fwd_kernel<8, 16>), grid, dim3(128), 0, st, p);
+    else hipLaunchKernelGGL((wkv7::fwd_kernel<4, 16>), grid, dim3(256), 0, st, p);
+    return finish_launch();
+}
+
+int vrwkv_wkv7_backward_bf16(int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
+                             const void* z, const void* a, const void* dy, const float* s, const float* sa,
+                             void* dw, void* dq, void* dk, void* dv, void* dz, void* da, void* stream) {
+    int rc = check_common(B, T, H);
+    if (rc) return rc;
+    if (!w || !q || !k || !v || !z || !a || !dy || !s || !sa || !dw || !dq || !dk || !dv || !dz || !da) return VRWKV_EINVAL;
+    if (misaligned(w) || misaligned(q) || misaligned(k) || misaligned(v) || misaligned(z) || misaligned(a) ||
+        misaligned(dy) || misaligned(s) || misaligned(sa) || misaligned(dw) || misaligned(dq) || misaligned(dk) ||
+        misaligned(dv) || misaligned(dz) || misaligned(da))
+        return VRWKV_EALIGN;
+    wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
+                    (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
+                    (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((wkv7::bwd_kernel<8>), dim3((unsigned)((long)B * H)), dim3(256), 0, st, p);
+    return finish_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+"""ctypes binding of libvisualrwkv_hip.so (C-ABI declared in include/visualrwkv_hip.h).
+
+There is deliberately no fallback: if the library is missing or a symbol cannot be resolved the
+import of the operator fails with an error that says how to build it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from .build import LIB_PATH
+
+_c_int, _c_void_p = ctypes.c_int, ctypes.c_void_p
+
+# symbol -> (restype, argtypes); must list every function include/visualrwkv_hip.h declares
+PROTOTYPES = {
+    "vrwkv_abi_version": (_c_int, []),
+    "vrwkv_strerror": (ctypes.c_char_p, [_c_int]),
+    "vrwkv_wkv7_forward_bf16": (_c_int, [_c_int] * 3 + [_c_void_p] * 10),
+    "vrwkv_wkv7_backward_bf16": (_c_int, [_c_int] * 3 + [_c_void_p] * 16),
+    "vrwkv_wkv7_set_forward_variant": (_c_int, [_c_int]),
+    "vrwkv_debug_probe": (_c_int, [_c_int] + [_c_void_p] * 4),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} is missing. Build it with `python -m visualrwkv_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU or PyTorch fallback for the WKV7 operator.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().vrwkv_strerror(code).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {code})")

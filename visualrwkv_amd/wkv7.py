@@ -1,0 +1,151 @@
+"""The reference's native-operator surface for RWKV-7, backed by the gfx950 library.
+
+Mirrors VisualRWKV-v7/v7.00/src/model.py:38-70 and cuda/wkv7_op.cpp:21-29:
+
+* ``torch.ops.wind_backstepping.forward(w,q,k,v,z,a, y,s,sa)`` and ``.backward(...)`` with the
+  reference's schemas (mutable out-arguments), registered for the CUDA dispatch key (which is the
+  key of HIP tensors on PyTorch-ROCm).  Unlike the reference binding (raw data_ptr casts, legacy
+  default stream, no checks) the implementation validates dtype/shape/contiguity/device and
+  launches on PyTorch's *current* stream of the tensors' device, which is what makes overlapping
+  the WKV backward with RCCL traffic on a side stream legal.
+* ``WindBackstepping`` (autograd.Function), ``RUN_CUDA_RWKV7g``, ``CHUNK_LEN``, ``HEAD_SIZE`` with
+  the reference's names, argument order and assertions.
+
+The reference's own ``src/model.py`` works unchanged on top of this module if its import-time
+``load(name="wind_backstepping", sources=[...cu])`` line is replaced by
+``import visualrwkv_amd.wkv7``.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import hip_lib
+
+HEAD_SIZE = 64
+CHUNK_LEN = 16
+
+_FWD_SCHEMA = ("forward(Tensor w, Tensor q, Tensor k, Tensor v, Tensor z, Tensor a, "
+               "Tensor(a!) y, Tensor(b!) s, Tensor(c!) sa) -> ()")
+_BWD_SCHEMA = ("backward(Tensor w, Tensor q, Tensor k, Tensor v, Tensor z, Tensor a, Tensor dy, "
+               "Tensor s, Tensor sa, Tensor(a!) dw, Tensor(b!) dq, Tensor(c!) dk, Tensor(d!) dv, "
+               "Tensor(e!) dz, Tensor(f!) da) -> ()")
+
+
+def _check_act(name, t, B, T, H):
+    if t.dtype != torch.bfloat16:
+        raise TypeError(f"wind_backstepping: {name} must be bfloat16, got {t.dtype}")
+    if tuple(t.shape) != (B, T, H, HEAD_SIZE):
+        raise ValueError(f"wind_backstepping: {name} has shape {tuple(t.shape)}, expected {(B, T, H, HEAD_SIZE)}")
+    if not t.is_contiguous():
+        raise ValueError(f"wind_backstepping: {name} must be contiguous")
+
+
+def _check_state(s, sa, B, T, H, dev):
+    if s.dtype != torch.float32 or sa.dtype != torch.float32:
+        raise TypeError("wind_backstepping: s and sa must be float32")
+    if tuple(s.shape) != (B, H, T // CHUNK_LEN, HEAD_SIZE, HEAD_SIZE) or not s.is_contiguous():
+        raise ValueError(f"wind_backstepping: s must be contiguous (B,H,T/{CHUNK_LEN},64,64), got {tuple(s.shape)}")
+    if tuple(sa.shape) != (B, T, H, HEAD_SIZE) or not sa.is_contiguous():
+        raise ValueError(f"wind_backstepping: sa must be contiguous (B,T,H,64), got {tuple(sa.shape)}")
+    if s.device != dev or sa.device != dev:
+        raise ValueError("wind_backstepping: all tensors must live on the same device")
+
+
+def _dims(w):
+    if w.dim() != 4 or w.shape[3] != HEAD_SIZE:
+        raise ValueError(f"wind_backstepping: expected (B,T,H,{HEAD_SIZE}) activations, got {tuple(w.shape)}")
+    B, T, H, _ = w.shape
+    if T % CHUNK_LEN != 0:
+        raise ValueError(f"wind_backstepping: T={T} must be a multiple of {CHUNK_LEN}")
+    return B, T, H
+
+
+def _forward_hip(w, q, k, v, z, a, y, s, sa):
+    B, T, H = _dims(w)
+    for n, t in zip("wqkvzay", (w, q, k, v, z, a, y)):
+        _check_act(n, t, B, T, H)
+        if t.device != w.device:
+            raise ValueError("wind_backstepping: all tensors must live on the same device")
+    _check_state(s, sa, B, T, H, w.device)
+    lib = hip_lib.load()
+    with torch.cuda.device(w.device):
+        stream = torch.cuda.current_stream(w.device).cuda_stream
+        rc = lib.vrwkv_wkv7_forward_bf16(B, T, H, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                         z.data_ptr(), a.data_ptr(), y.data_ptr(), s.data_ptr(), sa.data_ptr(),
+                                         stream)
+    hip_lib.check(rc, "vrwkv_wkv7_forward_bf16")
+
+
+def _backward_hip(w, q, k, v, z, a, dy, s, sa, dw, dq, dk, dv, dz, da):
+    B, T, H = _dims(w)
+    names = ("w", "q", "k", "v", "z", "a", "dy", "dw", "dq", "dk", "dv", "dz", "da")
+    for n, t in zip(names, (w, q, k, v, z, a, dy, dw, dq, dk, dv, dz, da)):
+        _check_act(n, t, B, T, H)
+        if t.device != w.device:
+            raise ValueError("wind_backstepping: all tensors must live on the same device")
+    _check_state(s, sa, B, T, H, w.device)
+    lib = hip_lib.load()
+    with torch.cuda.device(w.device):
+        stream = torch.cuda.current_stream(w.device).cuda_stream
+        rc = lib.vrwkv_wkv7_backward_bf16(B, T, H, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                          z.data_ptr(), a.data_ptr(), dy.data_ptr(), s.data_ptr(), sa.data_ptr(),
+                                          dw.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                          dz.data_ptr(), da.data_ptr(), stream)
+    hip_lib.check(rc, "vrwkv_wkv7_backward_bf16")
+
+
+def _no_cpu(*args):
+    raise NotImplementedError(
+        "wind_backstepping has no CPU implementation (neither does the reference: cuda/wkv7_op.cpp:26 "
+        "registers the CUDA key only). Move the tensors to an MI355X device.")
+
+
+def _register():
+    try:
+        lib = torch.library.Library("wind_backstepping", "DEF")
+    except RuntimeError as e:  # namespace already defined by another loader
+        raise RuntimeError("torch.ops.wind_backstepping is already defined in this process; "
+                           "do not load the reference's CUDA extension next to visualrwkv_amd") from e
+    lib.define(_FWD_SCHEMA)
+    lib.define(_BWD_SCHEMA)
+    lib.impl("forward", _forward_hip, "CUDA")
+    lib.impl("backward", _backward_hip, "CUDA")
+    lib.impl("forward", _no_cpu, "CPU")
+    lib.impl("backward", _no_cpu, "CPU")
+    return lib
+
+
+_LIB = _register()
+
+
+class WindBackstepping(torch.autograd.Function):
+    """src/model.py:45-65 (same asserts, same saved tensors, same allocation pattern)."""
+
+    @staticmethod
+    def forward(ctx, w, q, k, v, z, b):
+        B, T, H, C = w.shape
+        assert T % CHUNK_LEN == 0
+        assert all(i.dtype == torch.bfloat16 for i in [w, q, k, v, z, b])
+        assert all(i.is_contiguous() for i in [w, q, k, v, z, b])
+        y = torch.empty_like(v)
+        s = torch.empty(B, H, T // CHUNK_LEN, C, C, dtype=torch.float32, device=w.device)
+        sa = torch.empty(B, T, H, C, dtype=torch.float32, device=w.device)
+        torch.ops.wind_backstepping.forward(w, q, k, v, z, b, y, s, sa)
+        ctx.save_for_backward(w, q, k, v, z, b, s, sa)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        assert all(i.dtype == torch.bfloat16 for i in [dy])
+        assert all(i.is_contiguous() for i in [dy])
+        w, q, k, v, z, b, s, sa = ctx.saved_tensors
+        dw, dq, dk, dv, dz, db = [torch.empty_like(x) for x in [w, q, k, v, z, b]]
+        torch.ops.wind_backstepping.backward(w, q, k, v, z, b, dy, s, sa, dw, dq, dk, dv, dz, db)
+        return dw, dq, dk, dv, dz, db
+
+
+def RUN_CUDA_RWKV7g(q, w, k, v, a, b):
+    """src/model.py:67-70: (B,T,HC) views -> (B,T,H,64); note the (w,q,...) argument re-order."""
+    B, T, HC = q.shape
+    q, w, k, v, a, b = [i.view(B, T, HC // 64, 64) for i in [q, w, k, v, a, b]]
+    return WindBackstepping.apply(w, q, k, v, a, b).view(B, T, HC)
