@@ -51,7 +51,8 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H,
                              void* stream);
 
 /* Launch-shape override for benchmarking/tests: variant < 0 restores the automatic choice.
- * forward variants: 0 = 1 wave/head (4x16 lane tiles), 1 = 2 waves/head, 2 = 4 waves/head. */
+ * forward variants: 0/1/2 = sequential VALU kernel with 1/2/4 waves per head, 3 = chunked bf16x3
+ * MFMA kernel (the default). */
 int vrwkv_wkv7_set_forward_variant(int variant);
 
 /* Hardware probe for the GPU tests (MFMA lane maps, cross-lane primitives); one wave.

@@ -2,6 +2,7 @@
 // emulator.  TEST INFRASTRUCTURE ONLY -- built by tests/emu/build.py into tests/emu/libemu_kernels.so.
 #include <gfx950_prims.h>   // resolves to tests/emu/gfx950_prims.h (-I order)
 #include <wkv7_kernels.h>
+#include <wkv7_chunked.h>
 
 extern "C" {
 
@@ -12,7 +13,8 @@ int emu_wkv7_forward(int B, int T, int H, const void* w, const void* q, const vo
     dim3 grid((unsigned)(B * H));
     if (variant == 0) emu::launch(grid, dim3(64), [&] { wkv7::fwd_kernel<16, 8>(p); });
     else if (variant == 1) emu::launch(grid, dim3(128), [&] { wkv7::fwd_kernel<8, 16>(p); });
-    else emu::launch(grid, dim3(256), [&] { wkv7::fwd_kernel<4, 16>(p); });
+    else if (variant == 2) emu::launch(grid, dim3(256), [&] { wkv7::fwd_kernel<4, 16>(p); });
+    else emu::launch(grid, dim3(256), [&] { wkv7c::fwd_kernel(p); });
     return 0;
 }
 

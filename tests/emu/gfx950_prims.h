@@ -23,6 +23,12 @@ DEVFN uint32_t f32_to_bf16_bits(float x) {
 }
 DEVFN uint32_t pack_bf16x2(float lo, float hi) { return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16); }
 
+DEVFN uint32_t cvt_pk_bf16(float x0, float x1) { return pack_bf16x2(x0, x1); }
+DEVFN void split_pk(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    hi = cvt_pk_bf16(x0, x1);
+    lo = cvt_pk_bf16(x0 - bf16_lo(hi), x1 - bf16_hi(hi));
+}
+
 DEVFN float fast_exp(float x) { return expf(x); }
 DEVFN float fast_rcp(float x) { return 1.0f / x; }
 DEVFN float fast_log(float x) { return logf(x); }
@@ -41,6 +47,11 @@ DEVFN uint32_t emu_wave_read(uint32_t x, int src) {
 }
 DEVFN float lane_xor(float x, int mask) { return __uint_as_float(emu_wave_read(__float_as_uint(x), lane_id() ^ mask)); }
 DEVFN float lane_bcast(float x, int src) { return __uint_as_float(emu_wave_read(__float_as_uint(x), src)); }
+template <int K> DEVFN float dpp_shr(float x) {
+    int l = lane_id();
+    uint32_t r = emu_wave_read(__float_as_uint(x), l - K);
+    return (l & 15) >= K ? __uint_as_float(r) : 0.f;
+}
 DEVFN float lane_xor1(float x) { return lane_xor(x, 1); }
 DEVFN float lane_xor2(float x) { return lane_xor(x, 2); }
 DEVFN float lane_half_mirror(float x) { int l = lane_id(); return __uint_as_float(emu_wave_read(__float_as_uint(x), (l & ~7) | (7 - (l & 7)))); }

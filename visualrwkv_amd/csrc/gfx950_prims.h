@@ -28,6 +28,20 @@ DEVFN uint32_t f32_to_bf16_bits(float x) {
 }
 DEVFN uint32_t pack_bf16x2(float lo, float hi) { return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16); }
 
+// packed RNE conversion (one v_cvt_pk_bf16_f32): element 0 = x0 (low half), element 1 = x1
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+DEVFN uint32_t cvt_pk_bf16(float x0, float x1) {
+    f32x2_t x = {x0, x1};
+    bf16x2_t b = __builtin_convertvector(x, bf16x2_t);
+    return *reinterpret_cast<uint32_t*>(&b);
+}
+// split a pair of f32 into hi = bf16(x) and lo = bf16(x - hi)  (x ~= hi + lo to ~2^-17 relative)
+DEVFN void split_pk(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    hi = cvt_pk_bf16(x0, x1);
+    lo = cvt_pk_bf16(x0 - bf16_lo(hi), x1 - bf16_hi(hi));
+}
+
 // ---------------------------------------------------------------- math
 DEVFN float fast_exp(float x) { return __expf(x); }          // v_exp_f32 path
 DEVFN float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -40,6 +54,10 @@ DEVFN float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 // row_mirror 0x140, row_half_mirror 0x141.
 template <int CTRL> DEVFN float dpp_mov(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+// row_shr:K inside each 16-lane row; lanes whose source falls outside the row read 0
+template <int K> DEVFN float dpp_shr(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x110 + K, 0xf, 0xf, false));
 }
 DEVFN float lane_xor1(float x) { return dpp_mov<0xB1>(x); }        // quad_perm [1,0,3,2]
 DEVFN float lane_xor2(float x) { return dpp_mov<0x4E>(x); }        // quad_perm [2,3,0,1]

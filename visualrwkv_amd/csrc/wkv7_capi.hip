@@ -4,6 +4,7 @@
 
 #include "../../include/visualrwkv_hip.h"
 #include <wkv7_kernels.h>
+#include <wkv7_chunked.h>
 
 namespace {
 
@@ -39,7 +40,7 @@ const char* vrwkv_strerror(int code) {
 }
 
 int vrwkv_wkv7_set_forward_variant(int variant) {
-    if (variant > 2) return VRWKV_EINVAL;
+    if (variant > 3) return VRWKV_EINVAL;
     g_fwd_variant = variant;
     return VRWKV_OK;
 }
@@ -57,11 +58,12 @@ int vrwkv_wkv7_forward_bf16(int B, int T, int H, const void* w, const void* q, c
     hipStream_t st = (hipStream_t)stream;
     const long heads = (long)B * H;
     int variant = g_fwd_variant;
-    if (variant < 0) variant = heads >= 1024 ? 0 : heads >= 512 ? 1 : 2;   // >= 1024 waves when possible
+    if (variant < 0) variant = 3;                                           // chunked MFMA kernel
     const dim3 grid((unsigned)heads);
     if (variant == 0) hipLaunchKernelGGL((wkv7::fwd_kernel<16, 8>), grid, dim3(64), 0, st, p);
     else if (variant == 1) hipLaunchKernelGGL((wkv7::fwd_kernel<8, 16>), grid, dim3(128), 0, st, p);
-    else hipLaunchKernelGGL((wkv7::fwd_kernel<4, 16>), grid, dim3(256), 0, st, p);
+    else if (variant == 2) hipLaunchKernelGGL((wkv7::fwd_kernel<4, 16>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(wkv7c::fwd_kernel, grid, dim3(256), 0, st, p);
     return finish_launch();
 }
 
