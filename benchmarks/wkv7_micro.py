@@ -34,7 +34,7 @@ def synth_inputs(B, T, H, device, seed=42):
     return [x.bfloat16().contiguous() for x in (w, q, k, v, -kk, kk * gate, dy)]
 
 
-def time_wkv7(B, T, H, iters=20, warmup=3, device="cuda:0", variant=-1):
+def time_wkv7(B, T, H, iters=20, warmup=3, device="cuda:0", variant=-1, bwd_variant=-1):
     from visualrwkv_amd import hip_lib
     lib = hip_lib.load()
     w, q, k, v, z, a, dy = synth_inputs(B, T, H, device)
@@ -44,6 +44,7 @@ def time_wkv7(B, T, H, iters=20, warmup=3, device="cuda:0", variant=-1):
     grads = [torch.empty_like(w) for _ in range(6)]
     st = torch.cuda.current_stream().cuda_stream
     lib.vrwkv_wkv7_set_forward_variant(variant)
+    lib.vrwkv_wkv7_set_backward_variant(bwd_variant)
 
     def fwd():
         rc = lib.vrwkv_wkv7_forward_bf16(B, T, H, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), z.data_ptr(),
@@ -70,6 +71,7 @@ def time_wkv7(B, T, H, iters=20, warmup=3, device="cuda:0", variant=-1):
 
     fwd_ms, bwd_ms = timeit(fwd), timeit(bwd)
     lib.vrwkv_wkv7_set_forward_variant(-1)
+    lib.vrwkv_wkv7_set_backward_variant(-1)
     elems = B * T * H * 64
     res = {
         "B": B, "T": T, "H": H, "elems": elems,

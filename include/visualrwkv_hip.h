@@ -54,6 +54,8 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H,
  * forward variants: 0/1/2 = sequential VALU kernel with 1/2/4 waves per head, 3 = chunked bf16x3
  * MFMA kernel (the default). */
 int vrwkv_wkv7_set_forward_variant(int variant);
+/* backward variants: 0 = sequential VALU kernel, 1 = chunked bf16x3 MFMA kernel (the default). */
+int vrwkv_wkv7_set_backward_variant(int variant);
 
 /* Hardware probe for the GPU tests (MFMA lane maps, cross-lane primitives); one wave.
  * which: 0 = 16x16x4 f32, 1 = 32x32x2 f32, 2 = 16x16x32 bf16, 3 = 32x32x16 bf16 (d = a*b, row-major

@@ -3,6 +3,7 @@
 #include <gfx950_prims.h>   // resolves to tests/emu/gfx950_prims.h (-I order)
 #include <wkv7_kernels.h>
 #include <wkv7_chunked.h>
+#include <wkv7_chunked_bwd.h>
 
 extern "C" {
 
@@ -26,6 +27,17 @@ int emu_wkv7_backward(int B, int T, int H, const void* w, const void* q, const v
                     (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
     emu::launch(dim3((unsigned)(B * H)), dim3(256), [&] { wkv7::bwd_kernel<8>(p); });
     return 0;
+}
+
+int emu_wkv7_backward_chunked(int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
+                              const void* z, const void* a, const void* dy, const float* s, const float* sa,
+                              void* dw, void* dq, void* dk, void* dv, void* dz, void* da) {
+    wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
+                    (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
+                    (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
+    static_assert(sizeof(wkv7c::LdsB) <= 160 * 1024, "LDS budget");
+    emu::launch(dim3((unsigned)(B * H)), dim3(256), [&] { wkv7c::bwd_kernel(p); });
+    return (int)sizeof(wkv7c::LdsB);
 }
 
 }  // extern "C"

@@ -52,6 +52,11 @@ template <int K> DEVFN float dpp_shr(float x) {
     uint32_t r = emu_wave_read(__float_as_uint(x), l - K);
     return (l & 15) >= K ? __uint_as_float(r) : 0.f;
 }
+template <int K> DEVFN float dpp_shl(float x) {
+    int l = lane_id();
+    uint32_t r = emu_wave_read(__float_as_uint(x), l + K);
+    return (l & 15) + K <= 15 ? __uint_as_float(r) : 0.f;
+}
 DEVFN float lane_xor1(float x) { return lane_xor(x, 1); }
 DEVFN float lane_xor2(float x) { return lane_xor(x, 2); }
 DEVFN float lane_half_mirror(float x) { int l = lane_id(); return __uint_as_float(emu_wave_read(__float_as_uint(x), (l & ~7) | (7 - (l & 7)))); }
@@ -142,6 +147,8 @@ DEVFN f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     emu::wave_barrier();
     return d;
 }
+
+DEVFN char* dyn_lds() { static __attribute__((aligned(16))) char buf[160 * 1024]; return buf; }
 
 DEVFN void block_sync() { emu::block_barrier(); }
 DEVFN void wave_lds_fence() { emu::wave_barrier(); }

@@ -60,13 +60,18 @@ def test_forward_parity(hip_lib, dev, B, T, H, variant):
     assert rel_rms(sa.cpu(), sar) < 2e-5
 
 
+@pytest.mark.parametrize("variant", [0, 1, -1])
 @pytest.mark.parametrize("B,T,H", [(1, 16, 1), (2, 64, 3), (1, 384, 12), (3, 208, 5)])
-def test_backward_parity(hip_lib, dev, B, T, H):
+def test_backward_parity(hip_lib, dev, B, T, H, variant):
     w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=B * 77 + T + H)
     _, sr, sar = wkv7_c.forward(w, q, k, v, z, a)
     ref = wkv7_c.backward(w, q, k, v, z, a, dy, sr, sar)
-    outs = _capi_backward(hip_lib, *[x.to(dev) for x in (w, q, k, v, z, a, dy, sr, sar)])
-    torch.cuda.synchronize()
+    hip_lib.vrwkv_wkv7_set_backward_variant(variant)
+    try:
+        outs = _capi_backward(hip_lib, *[x.to(dev) for x in (w, q, k, v, z, a, dy, sr, sar)])
+        torch.cuda.synchronize()
+    finally:
+        hip_lib.vrwkv_wkv7_set_backward_variant(-1)
     for n, o, r in zip(NAMES, outs, ref):
         assert rel_rms(o.float().cpu(), r.float()) < TOL, n
 

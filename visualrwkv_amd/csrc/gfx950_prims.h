@@ -59,6 +59,10 @@ template <int CTRL> DEVFN float dpp_mov(float x) {
 template <int K> DEVFN float dpp_shr(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x110 + K, 0xf, 0xf, false));
 }
+// row_shl:K (lane t reads lane t+K of its 16-lane row; 0 beyond the row end)
+template <int K> DEVFN float dpp_shl(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x100 + K, 0xf, 0xf, false));
+}
 DEVFN float lane_xor1(float x) { return dpp_mov<0xB1>(x); }        // quad_perm [1,0,3,2]
 DEVFN float lane_xor2(float x) { return dpp_mov<0x4E>(x); }        // quad_perm [2,3,0,1]
 DEVFN float lane_half_mirror(float x) { return dpp_mov<0x141>(x); }  // i <-> 7-i   inside each 8 lanes
@@ -89,6 +93,11 @@ DEVFN f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) { return __builtin_amd
 DEVFN f32x4 mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 // 32x32x16 bf16: A[i=l&31][k=(l>>5)*8+e], B[k=(l>>5)*8+e][j=l&31]; C/D as 32x32x2.
 DEVFN f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+// ---------------------------------------------------------------- dynamic LDS
+// All LDS of a kernel that needs more than the 64 KB static limit lives in this one array.
+extern __shared__ __attribute__((aligned(16))) char vrwkv_dyn_lds[];
+DEVFN char* dyn_lds() { return vrwkv_dyn_lds; }
 
 // ---------------------------------------------------------------- sync
 DEVFN void block_sync() { __syncthreads(); }

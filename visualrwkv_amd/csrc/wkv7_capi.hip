@@ -5,10 +5,12 @@
 #include "../../include/visualrwkv_hip.h"
 #include <wkv7_kernels.h>
 #include <wkv7_chunked.h>
+#include <wkv7_chunked_bwd.h>
 
 namespace {
 
 int g_fwd_variant = -1;
+int g_bwd_variant = -1;
 
 inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 
@@ -42,6 +44,12 @@ const char* vrwkv_strerror(int code) {
 int vrwkv_wkv7_set_forward_variant(int variant) {
     if (variant > 3) return VRWKV_EINVAL;
     g_fwd_variant = variant;
+    return VRWKV_OK;
+}
+
+int vrwkv_wkv7_set_backward_variant(int variant) {
+    if (variant > 1) return VRWKV_EINVAL;
+    g_bwd_variant = variant;
     return VRWKV_OK;
 }
 
@@ -81,7 +89,19 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H, const void* w, const void* q, 
                     (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
                     (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((wkv7::bwd_kernel<8>), dim3((unsigned)((long)B * H)), dim3(256), 0, st, p);
+    const dim3 grid((unsigned)((long)B * H));
+    if (g_bwd_variant == 0) {
+        hipLaunchKernelGGL((wkv7::bwd_kernel<8>), grid, dim3(256), 0, st, p);
+    } else {
+        static bool attr_set = false;     // > 64 KB of LDS needs the opt-in once per process
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::bwd_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsB));
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(wkv7c::bwd_kernel, grid, dim3(256), sizeof(wkv7c::LdsB), st, p);
+    }
     return finish_launch();
 }
 

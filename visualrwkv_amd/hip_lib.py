@@ -19,6 +19,7 @@ PROTOTYPES = {
     "vrwkv_wkv7_forward_bf16": (_c_int, [_c_int] * 3 + [_c_void_p] * 10),
     "vrwkv_wkv7_backward_bf16": (_c_int, [_c_int] * 3 + [_c_void_p] * 16),
     "vrwkv_wkv7_set_forward_variant": (_c_int, [_c_int]),
+    "vrwkv_wkv7_set_backward_variant": (_c_int, [_c_int]),
     "vrwkv_debug_probe": (_c_int, [_c_int] + [_c_void_p] * 4),
 }
 
