@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""Training-step benchmark of the VisualRWKV-7 hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+One step = ViT encode (frozen SigLIP + DINOv2) -> pool -> projector -> scatter -> RWKV-7 forward ->
+shifted CE (+L2Wrap) -> backward -> bucketed reduce-scatter -> clip 1.0 -> fused AdamW -> all-gather, on a
+synthetic LLaVA-style batch (576 image tokens + 2048 text tokens = 2624 tokens per sample, bf16), random-init
+weights of the VisualRWKV-7 1.5B architecture (L24 C2048 H32, vocab 65536).  Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MODELS = {   # sizes of the RWKV-x070 checkpoints the reference README points to
+    "1b5": dict(n_layer=24, n_embd=2048),
+    "0b4": dict(n_layer=24, n_embd=1024),
+    "0b1": dict(n_layer=12, n_embd=768),
+}
+FWD_B, BWD_B = 34, 46          # algorithmic bytes per bf16 element at chunk length 16
+HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md
+
+
+def build_args(name, ctx_len, n_img_tokens, towers, grad_cp, fused):
+    m = MODELS[name]
+    return SimpleNamespace(n_layer=m["n_layer"], n_embd=m["n_embd"], dim_att=m["n_embd"], head_size_a=64,
+                           head_size_divisor=8, vocab_size=65536, dropout=0, grad_cp=grad_cp, ctx_len=ctx_len,
+                           load_model="", num_token_per_image=n_img_tokens, proj_type="mlp", vision_towers=towers,
+                           vision_image_size=448, vision_tower_kwargs=None, weight_decay=0.0, fused=fused,
+                           check_image_tokens=False)
+
+
+def synthetic_batch(B, ctx_len, n_img, towers, device, seed):
+    """ids uniform in [0,65535) with a run of n_img image placeholders after a 4-token prefix,
+    labels -100 on the first 60 %, pixels N(0,1) bf16."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    ids = torch.randint(0, 65535, (B, ctx_len), device=device, generator=g)
+    ids[:, 4:4 + n_img] = 65535
+    labels = ids.clone()
+    labels[:, : int(ctx_len * 0.6)] = -100
+    labels[ids == 65535] = -100
+    images = {}
+    for t in towers:
+        side = 1024 if t == "sam" else 448
+        images[t] = torch.randn(B, 3, side, side, device=device, generator=g).bfloat16()
+    return {"input_ids": ids, "labels": labels, "images": images, "sample_id": [str(i) for i in range(B)]}
+
+
+def cpu_baseline(n_embd, T):
+    """CPU leg: one RWKV-7 block (time-mix incl. the WKV7 C oracle + channel-mix) forward+backward in fp32 on
+    the host cores, B=1 at the bench sequence length; reported as tokens/s for a 24-layer stack of such
+    blocks (head, loss, ViT and optimizer excluded -- they only make the CPU slower)."""
+    from oracle import rwkv7_cpu, wkv7_c
+    from visualrwkv_amd.rwkv7 import Block
+    cores = min(os.cpu_count() or 1, 64)        # more torch threads than this only adds contention on the 256-thread host
+    torch.set_num_threads(cores)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    wkv7_c.load()
+    a = SimpleNamespace(n_layer=24, n_embd=n_embd, dim_att=n_embd, head_size_a=64, head_size_divisor=8, dropout=0, grad_cp=0)
+    blk = Block(a, 1)
+    with torch.no_grad():
+        for p in blk.parameters():
+            if float(p.abs().sum()) == 0.0:
+                p.normal_(0, 0.02)
+    st = {"b." + k: v.detach().requires_grad_(True) for k, v in blk.state_dict().items()}
+    x = (torch.randn(1, T, n_embd) * 0.5).requires_grad_(True)
+    vf = torch.randn(1, T, n_embd) * 0.5
+    times = []
+    for it in range(2):
+        t0 = time.perf_counter()
+        y, _ = rwkv7_cpu.block(st, "b.", x, vf, 1, n_embd // 64)
+        y.sum().backward()
+        times.append(time.perf_counter() - t0)
+    t = min(times[1:])
+    return {"value": T / (24 * t), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"1 of 24 RWKV-7 1.5B blocks (Tmix with the C WKV7 oracle + CMix), fwd+bwd, fp32, B=1 T={T}; "
+                      f"{t:.2f} s per block, scaled x24; head/loss/ViT/optimizer not included"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="1b5", choices=list(MODELS))
+    ap.add_argument("--micro-bsz", type=int, default=8)
+    ap.add_argument("--ctx-len", type=int, default=2624)          # 576 image + 2048 text tokens
+    ap.add_argument("--img-tokens", type=int, default=576)
+    ap.add_argument("--towers", default="dino,siglip")
+    ap.add_argument("--grad-cp", type=int, default=0)
+    ap.add_argument("--fused", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    from visualrwkv_amd import build, wkv7
+    build.build()
+    from visualrwkv_amd.dp import Zero1Engine
+    from visualrwkv_amd.visual import VisualRWKV
+    towers = tuple(t for t in a.towers.split(",") if t)
+    args = build_args(a.model, a.ctx_len, a.img_tokens, towers, a.grad_cp, bool(a.fused))
+    torch.manual_seed(42)
+    with torch.device(dev):
+        model = VisualRWKV(args)
+    with torch.no_grad():      # random-init: make the zero-initialised projections non-degenerate
+        for n, p in model.rwkv.named_parameters():
+            if p.dim() >= 2 and float(p.abs().max()) == 0.0:
+                p.normal_(0, 0.01)
+    model = model.to(torch.bfloat16)
+    model.freeze_emb()         # fine-tune recipe: ViT and embedding frozen (train.py:196, model.py:349)
+    engine = Zero1Engine(model, lr=2e-5, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0, grad_clip=1.0, bucket_mb=200.0)
+    batch = synthetic_batch(a.micro_bsz, a.ctx_len, a.img_tokens, towers, dev, seed=1000 + rank)
+
+    def step():
+        engine.zero_grad()
+        loss = model.training_step(batch)
+        loss.backward()
+        engine.step(2e-5)
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    wkv7.EVENT_LOG = [] if rank == 0 else None
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    log, wkv7.EVENT_LOG = wkv7.EVENT_LOG, None
+    tmax = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    tokens = world * a.micro_bsz * a.ctx_len * a.steps
+
+    if rank == 0:
+        out = {
+            "metric": "train tokens/sec/node VisualRWKV-7 1B5 bf16", "value": tokens / dt, "unit": "tokens/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"VisualRWKV-7 {a.model} + {'+'.join(towers)} ViT, {a.img_tokens} img + {a.ctx_len - a.img_tokens} text tokens, "
+                                   f"full train step (fwd+bwd+ZeRO-1 AdamW)", "model": f"VisualRWKV-7 {a.model}",
+                       "global_batch": world * a.micro_bsz, "seq_len": a.ctx_len, "parallelism": f"dp{world}",
+                       "grad_cp": a.grad_cp, "fused_elementwise": bool(a.fused), "loss": float(loss.detach())},
+        }
+        # roofline of the dominant hot-path kernel (WKV7 backward), HIP events on the launch stream
+        kinds = {}
+        for kind, e0, e1, elems in log:
+            kinds.setdefault(kind, []).append((e0.elapsed_time(e1), elems))
+        if "bwd" in kinds:
+            ms = sum(x for x, _ in kinds["bwd"]) / len(kinds["bwd"])
+            elems = kinds["bwd"][0][1]
+            ach = elems * BWD_B / ms / 1e6
+            out["roofline"] = {"bound": "hbm", "kernel": "wkv7c::bwd_kernel", "achieved": ach, "peak": HBM_PEAK_GBPS,
+                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                               "avg_ms": ms, "launches": len(kinds["bwd"]), "algorithmic_bytes": elems * BWD_B}
+            if "fwd" in kinds:
+                msf = sum(x for x, _ in kinds["fwd"]) / len(kinds["fwd"])
+                out["roofline"]["fwd_kernel"] = {"kernel": "wkv7c::fwd_kernel", "avg_ms": msf,
+                                                 "achieved": elems * FWD_B / msf / 1e6, "frac": elems * FWD_B / msf / 1e6 / HBM_PEAK_GBPS}
+            pmc = os.path.join(ROOT, "profiles", "wkv7_pmc.json")
+            if os.path.exists(pmc):
+                rec = json.load(open(pmc)).get(f"bwd_B{a.micro_bsz}_T{a.ctx_len}_H{args.n_embd // 64}")
+                if rec:
+                    out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.n_embd, a.ctx_len)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

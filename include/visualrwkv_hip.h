@@ -57,6 +57,18 @@ int vrwkv_wkv7_set_forward_variant(int variant);
 /* backward variants: 0 = sequential VALU kernel, 1 = chunked bf16x3 MFMA kernel (the default). */
 int vrwkv_wkv7_set_backward_variant(int variant);
 
+/* Fused AdamW step on a flat ZeRO-1 shard (replaces DeepSpeed's FusedAdam(adam_w_mode=True) that the
+ * reference configures in VisualRWKV-v7/v7.00/src/model.py:410): fp32 master/m/v, bf16 gradient in, bf16
+ * parameter out, gradient pre-scaled by grad_scale (clip coefficient / world size), bias correction for
+ * `step` (1-based).  Elements whose global index (global_offset + i) is >= wd_boundary get no weight
+ * decay (model.py:391-393).  n % 4 == 0. */
+int vrwkv_adamw_step_bf16(long n, float* master, float* m, float* v, const void* grad, void* param,
+                          float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                          float grad_scale, long global_offset, long wd_boundary, void* stream);
+
+/* out[0] += sum of squares of a bf16 buffer (n % 8 == 0); used for gradient_clip_val=1.0 (train.py:92). */
+int vrwkv_sqnorm_bf16(long n, const void* x, float* out, void* stream);
+
 /* Hardware probe for the GPU tests (MFMA lane maps, cross-lane primitives); one wave.
  * which: 0 = 16x16x4 f32, 1 = 32x32x2 f32, 2 = 16x16x32 bf16, 3 = 32x32x16 bf16 (d = a*b, row-major
  * f32 operands), 4 = cross-lane primitives (a: 64 floats, d: 384 floats). */

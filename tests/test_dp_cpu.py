@@ -1,0 +1,93 @@
+"""ZeRO-1 engine on CPU: single process against torch.optim.AdamW, and world_size 2 over gloo against the
+single-process result on the concatenated batch (the N>1 path of bench.py)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model(seed=0):
+    torch.manual_seed(seed)
+    m = nn.Sequential(nn.Linear(24, 40), nn.LayerNorm(40), nn.Tanh(), nn.Linear(40, 8))
+    return m
+
+
+def _data(n=16, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, 24, generator=g), torch.randn(n, 8, generator=g)
+
+
+def _loss(m, x, y):
+    return ((m(x) - y) ** 2).mean()
+
+
+def test_single_process_matches_torch_adamw():
+    from visualrwkv_amd.dp import Zero1Engine
+    ref = _model()
+    mine = _model()
+    x, y = _data()
+    wd_params = [p for p in ref.parameters() if len(p.squeeze().shape) >= 2]
+    no_wd = [p for p in ref.parameters() if len(p.squeeze().shape) < 2]
+    opt = torch.optim.AdamW([{"params": wd_params, "weight_decay": 0.1}, {"params": no_wd, "weight_decay": 0.0}],
+                            lr=1e-2, betas=(0.9, 0.99), eps=1e-8)
+    eng = Zero1Engine(mine, lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.1, grad_clip=1.0, bucket_mb=0.001)
+    assert len(eng.buckets) > 1
+    for _ in range(5):
+        opt.zero_grad(); _loss(ref, x, y).backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+        opt.step()
+        eng.zero_grad(); _loss(mine, x, y).backward(); eng.step()
+    for a, b in zip(ref.parameters(), mine.parameters()):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from visualrwkv_amd.dp import Zero1Engine
+    m = _model()
+    x, y = _data()
+    xs, ys = x[rank::world], y[rank::world]                 # rank-strided shard of the global batch
+    eng = Zero1Engine(m, lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.1, grad_clip=1.0, bucket_mb=0.001)
+    for _ in range(4):
+        eng.zero_grad(); _loss(m, xs, ys).backward(); eng.step()
+    torch.save([p.detach().clone() for p in m.parameters()], os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_matches_single_process(tmp_path):
+    from visualrwkv_amd.dp import Zero1Engine
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "r0.pt"); r1 = torch.load(tmp_path / "r1.pt")
+    for a, b in zip(r0, r1):
+        assert torch.equal(a, b)                            # replicas stay identical
+    m = _model()
+    x, y = _data()
+    eng = Zero1Engine(m, lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.1, grad_clip=1.0, bucket_mb=0.001)
+    for _ in range(4):
+        eng.zero_grad(); _loss(m, x, y).backward(); eng.step()
+    for a, b in zip(r0, m.parameters()):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+
+
+def test_schedule_and_sampler_match_reference_formulas():
+    from visualrwkv_amd.dp import largest_3n_plus_2_prime, lr_wd_schedule, rank_strided_sample
+    # values of src/trainer.py:24-38 for the shipped 0.1B script (lr 6e-4 -> 6e-5... here generic numbers)
+    lr0, _ = lr_wd_schedule(0, 6e-4, 6e-5, 100, 0, 10, 1000)
+    assert lr0 == pytest.approx(6e-4 * 0.1, rel=1e-3)
+    lr_mid, _ = lr_wd_schedule(5000, 6e-4, 6e-5, 100, 0, 10, 1000)
+    assert lr_mid == pytest.approx(6e-5 + (6e-4 - 6e-5) * 0.5 * (1 + __import__("math").cos(__import__("math").pi * (5000 - 100 + 1) / 9900)), rel=1e-9)
+    lr_end, _ = lr_wd_schedule(10000, 6e-4, 6e-5, 100, 0, 10, 1000)
+    assert lr_end == pytest.approx(6e-5)
+    assert largest_3n_plus_2_prime(665298) == 665279 and largest_3n_plus_2_prime(10) == 5
+    idx, rev = rank_strided_sample(0, 3, 1, 8, 8000, 665279)
+    assert idx == (25 ** 3) % 665279 and rev is False

@@ -1,0 +1,90 @@
+// Streaming (HBM-bound) kernels around the WKV7 operator: fused AdamW on a ZeRO-1 shard, squared-norm
+// reduction for gradient clipping.  16-byte accesses, grid-stride, one pass over the data.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/visualrwkv_hip.h"
+#include <gfx950_prims.h>
+
+namespace {
+
+// AdamW (decoupled weight decay, bias-corrected) on a flat shard:
+//   DeepSpeed FusedAdam(adam_w_mode=True) as configured by the reference (src/model.py:410):
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr * ( (m/bc1) / (sqrt(v/bc2) + eps) + wd p )
+// master/m/v fp32, gradient and published parameter bf16.  Elements with global index >= wd_boundary get
+// no weight decay (tensors that are < 2-D after squeeze(), src/model.py:391-393).
+__global__ __launch_bounds__(256) void adamw_kernel(long n, float* __restrict__ master, float* __restrict__ m,
+                                                    float* __restrict__ v, const uint16_t* __restrict__ grad,
+                                                    uint16_t* __restrict__ param, float lr, float b1, float b2, float eps,
+                                                    float wd, float inv_bc1, float inv_sqrt_bc2, float grad_scale,
+                                                    long global_offset, long wd_boundary) {
+    const long nvec = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        float4 p4 = reinterpret_cast<float4*>(master)[i];
+        float4 m4 = reinterpret_cast<float4*>(m)[i];
+        float4 v4 = reinterpret_cast<float4*>(v)[i];
+        const uint2 g2 = reinterpret_cast<const uint2*>(grad)[i];
+        float p[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+        const float g[4] = {bf16_lo(g2.x) * grad_scale, bf16_hi(g2.x) * grad_scale, bf16_lo(g2.y) * grad_scale, bf16_hi(g2.y) * grad_scale};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float decay = (global_offset + 4 * i + e) < wd_boundary ? wd : 0.f;
+            mm[e] = b1 * mm[e] + (1.f - b1) * g[e];
+            vv[e] = b2 * vv[e] + (1.f - b2) * g[e] * g[e];
+            const float upd = (mm[e] * inv_bc1) / (sqrtf(vv[e]) * inv_sqrt_bc2 + eps) + decay * p[e];
+            p[e] -= lr * upd;
+        }
+        reinterpret_cast<float4*>(master)[i] = make_float4(p[0], p[1], p[2], p[3]);
+        reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        reinterpret_cast<uint2*>(param)[i] = make_uint2(cvt_pk_bf16(p[0], p[1]), cvt_pk_bf16(p[2], p[3]));
+    }
+}
+
+// out[0] += sum x^2 over a bf16 buffer (n % 8 == 0); one atomic per workgroup
+__global__ __launch_bounds__(256) void sqnorm_bf16_kernel(long n, const uint16_t* __restrict__ x, float* out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    const long nvec = n >> 3;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        const uint4 u = reinterpret_cast<const uint4*>(x)[i];
+        const float f[8] = {bf16_lo(u.x), bf16_hi(u.x), bf16_lo(u.y), bf16_hi(u.y), bf16_lo(u.z), bf16_hi(u.z), bf16_lo(u.w), bf16_hi(u.w)};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = fmaf(f[e], f[e], acc);
+    }
+    acc = group_sum<6>(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+int grid_for(long nvec) {
+    long b = (nvec + 255) / 256;
+    return (int)(b < 1 ? 1 : b > 2048 ? 2048 : b);      // <= 8 workgroups per CU, grid-stride the rest
+}
+
+}  // namespace
+
+extern "C" {
+
+int vrwkv_adamw_step_bf16(long n, float* master, float* m, float* v, const void* grad, void* param,
+                          float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                          float grad_scale, long global_offset, long wd_boundary, void* stream) {
+    if (n <= 0 || !master || !m || !v || !grad || !param || step < 1) return VRWKV_EINVAL;
+    if (n % 4 != 0) return VRWKV_ESHAPE;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, (hipStream_t)stream, n, master, m, v,
+                       (const uint16_t*)grad, (uint16_t*)param, lr, beta1, beta2, eps, weight_decay,
+                       (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale, global_offset, wd_boundary);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? VRWKV_OK : (int)e;
+}
+
+int vrwkv_sqnorm_bf16(long n, const void* x, float* out, void* stream) {
+    if (n <= 0 || !x || !out) return VRWKV_EINVAL;
+    if (n % 8 != 0) return VRWKV_ESHAPE;
+    hipLaunchKernelGGL(sqnorm_bf16_kernel, dim3(grid_for(n >> 3)), dim3(256), 0, (hipStream_t)stream, n, (const uint16_t*)x, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? VRWKV_OK : (int)e;
+}
+
+}  // extern "C"

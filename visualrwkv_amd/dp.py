@@ -1,0 +1,286 @@
+"""Data-parallel training engine with ZeRO-1 semantics for one node of MI355X (RCCL over xGMI).
+
+What the reference delegates to Lightning's DeepSpeedStrategy (`--strategy deepspeed_stage_1`, bf16,
+bucket size `ds_bucket_mb`, FusedAdam, gradient_clip_val=1.0; VisualRWKV-v7/v7.00/train.py:55,75-76,92,
+214-216 and src/model.py:390-410) is restated here MI355X-first:
+
+* one process per GPU; the model replica keeps its trainable parameters and gradients as views into two
+  flat bf16 buffers (weight-decayed tensors first, then the < 2-D ones -- src/model.py:391-393);
+* the flat buffer is cut into buckets (default 200 MB like `ds_bucket_mb`, train.py:55); as soon as the
+  backward has produced every gradient of a bucket, that bucket is reduce-scattered on a side HIP stream
+  (one RCCL reduce-scatter per bucket: every GPU sends 1/W of the bucket to each peer, so all seven xGMI
+  links of the mesh carry traffic, instead of a ring all-reduce that is bound by one link), overlapping the
+  remaining WKV7/GEMM backward, which launches on the compute stream (the WKV op uses the current stream);
+* each rank owns piece r of every bucket: fp32 master weights + Adam moments live only for that piece
+  (optimizer state sharded W ways);  gradient clipping needs one scalar all-reduce of the squared norm;
+* fused AdamW (HIP kernel, vrwkv_adamw_step_bf16) updates the piece and writes the bf16 parameters, which
+  are all-gathered back bucket by bucket.
+
+With world_size == 1 the collectives disappear and the same code path runs.  On CPU/gloo (tests) the
+reduce-scatter is emulated with all-reduce + slice and the optimizer uses a torch restatement of the kernel.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def lr_wd_schedule(real_step: int, lr_init: float, lr_final: float, warmup_steps: int, epoch_begin: int,
+                   epoch_count: int, epoch_steps: int, weight_decay: float = 0.0, weight_decay_final: float = -1.0):
+    """LR / weight-decay schedule of the reference's train_callback.on_train_batch_start
+    (src/trainer.py:24-49): cosine decay from lr_init to lr_final over (epoch_begin+epoch_count)*epoch_steps
+    steps with progress = (step - warmup + 1)/(total - warmup), multiplied by (0.1 + 0.9 step/warmup) during
+    warm-up; exponential weight-decay interpolation when weight_decay_final > 0.  Returns (lr, wd_now).
+    (Quirk kept by callers that mirror the reference: it writes `lr` only into the param groups whose
+    weight_decay is 0 and `wd_now` into the others, trainer.py:45-49.)"""
+    progress = 0.0
+    if lr_final == lr_init or epoch_count == 0:
+        lr = lr_init
+    else:
+        decay_total = (epoch_begin + epoch_count) * epoch_steps
+        progress = (real_step - warmup_steps + 1) / (decay_total - warmup_steps)
+        progress = min(1, max(0, progress))
+        cosine_decay = max(0.0, 0.5 * (1 + math.cos(math.pi * progress)))
+        lr = lr_final + (lr_init - lr_final) * cosine_decay
+    if real_step < warmup_steps:
+        lr = lr * (0.1 + 0.9 * real_step / warmup_steps)
+    if weight_decay_final > 0:
+        wd_now = weight_decay * math.exp(math.log(weight_decay_final / weight_decay) * progress)
+    else:
+        wd_now = weight_decay
+    return lr, wd_now
+
+
+class _Bucket:
+    __slots__ = ("start", "end", "piece", "pending", "n_params", "master", "m", "v", "work", "event")
+
+
+class Zero1Engine:
+    def __init__(self, model: torch.nn.Module, lr: float = 1e-4, betas=(0.9, 0.99), eps: float = 1e-8,
+                 weight_decay: float = 0.0, grad_clip: float = 1.0, bucket_mb: float = 200.0,
+                 process_group=None, overlap: bool = True):
+        self.model = model
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.grad_clip = grad_clip
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.step_count = 0
+        params = [p for p in model.parameters() if p.requires_grad]
+        assert params, "nothing to train"
+        self.device = params[0].device
+        self.dtype = params[0].dtype
+        self.on_gpu = self.device.type == "cuda"
+        self.overlap = overlap and self.on_gpu and self.world > 1
+        wd = [p for p in params if len(p.squeeze().shape) >= 2]
+        nowd = [p for p in params if len(p.squeeze().shape) < 2]
+        # later layers produce their gradients first: lay the flat buffer out in reverse registration order
+        # inside each group so that buckets fill front to back during the backward
+        ordered = wd[::-1] + nowd[::-1]
+        align = 8 * self.world                       # every piece 16-byte aligned in bf16
+        offs, total = [], 0
+        for p in ordered:
+            offs.append(total)
+            total += (p.numel() + 7) // 8 * 8
+        self.wd_boundary = sum((p.numel() + 7) // 8 * 8 for p in wd)
+        bucket_elems = max(int(bucket_mb * 1e6) // 2 // align * align, align)
+        total = (total + align - 1) // align * align
+        self.numel = total
+        self.flat_param = torch.zeros(total, dtype=self.dtype, device=self.device)
+        self.flat_grad = torch.zeros(total, dtype=self.dtype, device=self.device)
+        self.params = ordered
+        self.offsets = offs
+        with torch.no_grad():
+            for p, o in zip(ordered, offs):
+                self.flat_param[o:o + p.numel()].copy_(p.data.reshape(-1))
+                p.data = self.flat_param[o:o + p.numel()].view_as(p)
+                p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+        # buckets
+        self.buckets: List[_Bucket] = []
+        s = 0
+        while s < total:
+            b = _Bucket()
+            b.start, b.end = s, min(s + bucket_elems, total)
+            b.piece = (b.end - b.start) // self.world
+            ps = b.start + self.rank * b.piece
+            b.master = self.flat_param[ps:ps + b.piece].float().clone()
+            b.m = torch.zeros_like(b.master)
+            b.v = torch.zeros_like(b.master)
+            b.n_params, b.pending, b.work, b.event = 0, 0, None, None
+            self.buckets.append(b)
+            s = b.end
+        # which buckets does each parameter touch
+        self._param_buckets = []
+        for p, o in zip(ordered, offs):
+            first = o // bucket_elems
+            last = (o + max(p.numel(), 1) - 1) // bucket_elems
+            idx = list(range(first, min(last, len(self.buckets) - 1) + 1))
+            self._param_buckets.append(idx)
+            for i in idx:
+                self.buckets[i].n_params += 1
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        self._hooks = []
+        if self.world > 1:
+            for k, p in enumerate(ordered):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(k)))
+        self._sq = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._reset_pending()
+
+    # ------------------------------------------------------------------ gradient reduction
+    def _reset_pending(self):
+        for b in self.buckets:
+            b.pending = b.n_params
+            b.work, b.event = None, None
+
+    def _make_hook(self, k):
+        def hook(param):
+            g = param.grad
+            o = self.offsets[k]
+            if g.data_ptr() != self.flat_grad.data_ptr() + o * self.flat_grad.element_size():
+                # autograd replaced .grad (first accumulation): copy into the flat view and re-attach it
+                view = self.flat_grad[o:o + param.numel()].view_as(param)
+                view.copy_(g)
+                param.grad = view
+            for i in self._param_buckets[k]:
+                b = self.buckets[i]
+                b.pending -= 1
+                if b.pending == 0:
+                    self._launch_reduce(b)
+        return hook
+
+    def _launch_reduce(self, b: _Bucket):
+        if self.world == 1:
+            return
+        buf = self.flat_grad[b.start:b.end]
+        if self.overlap:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))
+            self.comm_stream.wait_event(ready)
+            with torch.cuda.stream(self.comm_stream):
+                self._reduce_scatter(buf, b)
+                b.event = torch.cuda.Event()
+                b.event.record(self.comm_stream)
+        else:
+            self._reduce_scatter(buf, b)
+
+    def _reduce_scatter(self, buf, b: _Bucket):
+        piece = buf[self.rank * b.piece:(self.rank + 1) * b.piece]
+        backend = dist.get_backend(self.pg)
+        if backend == "nccl":
+            dist.reduce_scatter_tensor(piece, buf, op=dist.ReduceOp.SUM, group=self.pg)   # in place on own piece
+        else:   # gloo has no reduce-scatter: all-reduce then keep the own slice (same result)
+            if buf.dtype == torch.bfloat16:
+                tmp = buf.float()
+                dist.all_reduce(tmp, group=self.pg)
+                buf.copy_(tmp)
+            else:
+                dist.all_reduce(buf, group=self.pg)
+
+    # ------------------------------------------------------------------ optimizer step
+    @torch.no_grad()
+    def step(self, lr: Optional[float] = None):
+        """Finish gradient reduction, clip to `grad_clip` (global L2 norm), AdamW on the owned pieces, publish
+        the updated bf16 parameters.  Returns the pre-clip global gradient norm."""
+        lr = self.lr if lr is None else lr
+        self.step_count += 1
+        if self.world > 1:
+            for b in self.buckets:                   # buckets whose hooks never all fired (unused params)
+                if b.pending > 0:
+                    self._launch_reduce(b)
+            if self.overlap:
+                for b in self.buckets:
+                    if b.event is not None:
+                        torch.cuda.current_stream(self.device).wait_event(b.event)
+        inv_world = 1.0 / self.world
+        # global gradient norm over the owned pieces (each element is owned by exactly one rank)
+        self._sq.zero_()
+        for b in self.buckets:
+            g = self._piece(self.flat_grad, b)
+            self._sqnorm(g, self._sq)
+        if self.world > 1:
+            dist.all_reduce(self._sq, group=self.pg)
+        gnorm = float(self._sq.sqrt()) * inv_world
+        scale = inv_world
+        if self.grad_clip and self.grad_clip > 0:
+            scale *= min(1.0, self.grad_clip / (gnorm + 1e-6))
+        for b in self.buckets:
+            self._adamw(b, lr, scale)
+        if self.world > 1:
+            for b in self.buckets:
+                buf = self.flat_param[b.start:b.end]
+                piece = buf[self.rank * b.piece:(self.rank + 1) * b.piece]
+                if dist.get_backend(self.pg) == "nccl":
+                    dist.all_gather_into_tensor(buf, piece, group=self.pg)          # in place (own slot = input)
+                else:   # gloo (CPU tests): bit-cast to int16, list form
+                    raw = buf.view(torch.int16) if buf.dtype == torch.bfloat16 else buf
+                    dist.all_gather(list(raw.chunk(self.world)), raw[self.rank * b.piece:(self.rank + 1) * b.piece].clone(), group=self.pg)
+        self._reset_pending()
+        return gnorm
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+
+    def _piece(self, flat, b: _Bucket):
+        s = b.start + self.rank * b.piece
+        return flat[s:s + b.piece]
+
+    def _sqnorm(self, g, out):
+        if self.on_gpu and g.dtype == torch.bfloat16 and g.numel() % 8 == 0:
+            from . import hip_lib
+            rc = hip_lib.load().vrwkv_sqnorm_bf16(g.numel(), g.data_ptr(), out.data_ptr(),
+                                                  torch.cuda.current_stream(self.device).cuda_stream)
+            hip_lib.check(rc, "vrwkv_sqnorm_bf16")
+        else:
+            out += g.float().pow(2).sum()
+
+    def _adamw(self, b: _Bucket, lr, scale):
+        g = self._piece(self.flat_grad, b)
+        p = self._piece(self.flat_param, b)
+        off = b.start + self.rank * b.piece
+        b1, b2 = self.betas
+        if self.on_gpu and g.dtype == torch.bfloat16:
+            from . import hip_lib
+            rc = hip_lib.load().vrwkv_adamw_step_bf16(
+                b.piece, b.master.data_ptr(), b.m.data_ptr(), b.v.data_ptr(), g.data_ptr(), p.data_ptr(),
+                lr, b1, b2, self.eps, self.weight_decay, self.step_count, scale, off, self.wd_boundary,
+                torch.cuda.current_stream(self.device).cuda_stream)
+            hip_lib.check(rc, "vrwkv_adamw_step_bf16")
+            return
+        # host restatement of the kernel (CPU tests of the distributed logic)
+        gf = g.float() * scale
+        b.m.mul_(b1).add_(gf, alpha=1 - b1)
+        b.v.mul_(b2).addcmul_(gf, gf, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** self.step_count, 1 - b2 ** self.step_count
+        idx = torch.arange(off, off + b.piece, device=g.device)
+        decay = torch.where(idx < self.wd_boundary, self.weight_decay, 0.0).to(torch.float32)
+        upd = (b.m / bc1) / ((b.v / bc2).sqrt() + self.eps) + decay * b.master
+        b.master.add_(upd, alpha=-lr)
+        p.copy_(b.master.to(p.dtype))
+
+
+def largest_3n_plus_2_prime(x: int) -> int:
+    """Largest prime p <= x with p % 3 == 2 (src/utils.py:29-45): cubing is then a bijection mod p."""
+    def is_prime(n):
+        if n < 2:
+            return False
+        i = 2
+        while i * i <= n:
+            if n % i == 0:
+                return False
+            i += 1
+        return True
+    for p in range(x, 1, -1):
+        if p % 3 == 2 and is_prime(p):
+            return p
+    return -1
+
+
+def rank_strided_sample(epoch: int, idx: int, rank: int, world: int, samples_per_epoch: int, magic_prime: int):
+    """Deterministic sample choice of the reference dataset (src/dataset.py:182-195):
+    step = epoch*samples_per_epoch + idx*world + rank ; index = step^3 mod magic_prime; the second pass
+    (step >= magic_prime) reads the reversed list.  Returns (index, use_reversed_list)."""
+    step = epoch * samples_per_epoch + idx * world + rank
+    return (step * step * step) % magic_prime, step >= magic_prime

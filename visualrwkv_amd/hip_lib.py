@@ -20,6 +20,8 @@ PROTOTYPES = {
     "vrwkv_wkv7_backward_bf16": (_c_int, [_c_int] * 3 + [_c_void_p] * 16),
     "vrwkv_wkv7_set_forward_variant": (_c_int, [_c_int]),
     "vrwkv_wkv7_set_backward_variant": (_c_int, [_c_int]),
+    "vrwkv_adamw_step_bf16": (_c_int, [ctypes.c_long] + [_c_void_p] * 5 + [ctypes.c_float] * 5 + [_c_int, ctypes.c_float, ctypes.c_long, ctypes.c_long, _c_void_p]),
+    "vrwkv_sqnorm_bf16": (_c_int, [ctypes.c_long, _c_void_p, _c_void_p, _c_void_p]),
     "vrwkv_debug_probe": (_c_int, [_c_int] + [_c_void_p] * 4),
 }
 

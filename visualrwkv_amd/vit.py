@@ -1,0 +1,304 @@
+"""Frozen vision towers that feed the image-to-language projector (forward only).
+
+Mirror of the reference's `SamDinoSigLIPViTBackbone` (VisualRWKV-v7/v7.00/src/vision.py:49-145):
+    dino   : timm `vit_large_patch14_reg4_dinov2.lvd142m`  @448 -> 1024 patch tokens x 1024
+    siglip : timm `vit_so400m_patch14_siglip_384`          @448 -> 1024 patch tokens x 1152
+    sam    : SAM ViT-B image encoder (src/sam.py)          @1024 -> 64x64x256 -> 32x32x1024
+each returning the output of its *second-to-last* block without the final norm and without prefix
+tokens (`get_intermediate_layers(n={depth-2})`, vision.py:75-81), concatenated on the channel axis.
+
+timm is a third-party dependency of the reference that is neither vendored nor pinned
+(Dockerfile:13) and is not installed here, so the two timm towers are re-stated from timm's
+published `VisionTransformer` (parameter names kept: patch_embed.proj, pos_embed, cls_token,
+reg_token, blocks.N.{norm1,attn.qkv,attn.proj,ls1.gamma,norm2,mlp.fc1,mlp.fc2,ls2.gamma}, norm) and
+pinned in tests against `transformers`' Siglip/Dinov2 modules; the SAM tower is pinned against the
+in-repo reference implementation (src/sam.py).  Softmax attention runs through
+`visualrwkv_amd.attention.attention` (MFMA flash kernel on gfx950).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .attention import attention
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden, act="gelu"):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+        self.approx = "tanh" if act == "gelu_tanh" else "none"
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x), approximate=self.approx))
+
+
+class _LayerScale(nn.Module):
+    def __init__(self, dim, init):
+        super().__init__()
+        self.gamma = nn.Parameter(init * torch.ones(dim))
+
+    def forward(self, x):
+        return x * self.gamma
+
+
+class _Attn(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.num_heads = heads
+        self.qkv = nn.Linear(dim, dim * 3)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        B, L, C = x.shape
+        qkv = self.qkv(x).view(B, L, 3, self.num_heads, C // self.num_heads)
+        o = attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2])          # (B, L, H, D) in and out
+        return self.proj(o.reshape(B, L, C))
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, heads, hidden, ls_init, act, eps):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = _Attn(dim, heads)
+        self.ls1 = _LayerScale(dim, ls_init) if ls_init is not None else nn.Identity()
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.mlp = _Mlp(dim, hidden, act)
+        self.ls2 = _LayerScale(dim, ls_init) if ls_init is not None else nn.Identity()
+
+    def forward(self, x):
+        x = x + self.ls1(self.attn(self.norm1(x)))
+        return x + self.ls2(self.mlp(self.norm2(x)))
+
+
+class _PatchEmbed(nn.Module):
+    """Non-overlapping patch embedding = one GEMM over unfolded patches (conv with stride = kernel)."""
+
+    def __init__(self, patch, in_chans, dim):
+        super().__init__()
+        self.patch = patch
+        self.proj = nn.Conv2d(in_chans, dim, kernel_size=patch, stride=patch)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        p = self.patch
+        gh, gw = H // p, W // p
+        x = x.view(B, C, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * p * p)
+        return F.linear(x, self.proj.weight.view(self.proj.weight.shape[0], -1), self.proj.bias)
+
+    @property
+    def num_patches_side(self):
+        return None
+
+
+class TimmViT(nn.Module):
+    """timm VisionTransformer subset: patch embed, learned abs pos-embed, optional cls/register tokens
+    (no_embed_class layout of DINOv2-reg), pre-LN blocks with optional LayerScale."""
+
+    def __init__(self, img_size=448, patch=14, dim=1024, depth=24, heads=16, mlp_hidden=4096,
+                 class_token=True, reg_tokens=0, ls_init: Optional[float] = None, act="gelu", eps=1e-6):
+        super().__init__()
+        self.embed_dim = dim
+        self.grid = img_size // patch
+        self.patch_embed = _PatchEmbed(patch, 3, dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, dim)) if class_token else None
+        self.reg_token = nn.Parameter(torch.zeros(1, reg_tokens, dim)) if reg_tokens else None
+        self.num_prefix_tokens = (1 if class_token else 0) + reg_tokens
+        self.pos_embed = nn.Parameter(torch.randn(1, self.grid * self.grid, dim) * 0.02)
+        self.blocks = nn.ModuleList([_Block(dim, heads, mlp_hidden, ls_init, act, eps) for _ in range(depth)])
+        self.norm = nn.LayerNorm(dim, eps=eps)   # present in checkpoints; not applied (norm=False)
+
+    def get_intermediate_layers(self, x, n: Sequence[int]):
+        """Patch tokens after block index max(n) (0-based), prefix tokens removed, no final norm."""
+        last = max(n)
+        x = self.patch_embed(x) + self.pos_embed
+        prefix = [t.expand(x.shape[0], -1, -1) for t in (self.cls_token, self.reg_token) if t is not None]
+        if prefix:
+            x = torch.cat(prefix + [x], dim=1)
+        for i, blk in enumerate(self.blocks):
+            x = blk(x)
+            if i == last:
+                break
+        return x[:, self.num_prefix_tokens:]
+
+    def forward(self, x):
+        return self.get_intermediate_layers(x, n={len(self.blocks) - 2})
+
+
+def dinov2_large_reg4(img_size=448, depth=24, dim=1024, heads=16):
+    return TimmViT(img_size, 14, dim, depth, heads, dim * 4, class_token=True, reg_tokens=4, ls_init=1e-5)
+
+
+def siglip_so400m(img_size=448, depth=27, dim=1152, heads=16, mlp_hidden=4304):
+    return TimmViT(img_size, 14, dim, depth, heads, mlp_hidden, class_token=False, reg_tokens=0, ls_init=None)
+
+
+# ------------------------------------------------------------------------------------------------
+# SAM ViT-B image encoder (src/sam.py:77-181), parameter names kept.
+# ------------------------------------------------------------------------------------------------
+class _LayerNorm2d(nn.Module):
+    def __init__(self, c, eps=1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.eps = eps
+
+    def forward(self, x):     # normalise over the channel axis of (B,C,H,W)
+        return F.layer_norm(x.permute(0, 2, 3, 1), (x.shape[1],), self.weight, self.bias, self.eps).permute(0, 3, 1, 2)
+
+
+class _SamMlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.lin1 = nn.Linear(dim, hidden)
+        self.lin2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.lin2(F.gelu(self.lin1(x)))
+
+
+def _rel_table(size: int, rel_pos: torch.Tensor) -> torch.Tensor:
+    """(size, size, C) table R[q, k] = rel_pos[q - k + size - 1]  (src/sam.py:359-389, equal q/k sizes)."""
+    want = 2 * size - 1
+    if rel_pos.shape[0] != want:
+        rel_pos = F.interpolate(rel_pos.t()[None], size=want, mode="linear")[0].t()
+    idx = torch.arange(size, device=rel_pos.device)
+    return rel_pos[(idx[:, None] - idx[None, :]) + (size - 1)]
+
+
+class _SamAttention(nn.Module):
+    def __init__(self, dim, heads, input_size):
+        super().__init__()
+        self.num_heads = heads
+        hd = dim // heads
+        self.qkv = nn.Linear(dim, dim * 3)
+        self.proj = nn.Linear(dim, dim)
+        self.rel_pos_h = nn.Parameter(torch.zeros(2 * input_size[0] - 1, hd))
+        self.rel_pos_w = nn.Parameter(torch.zeros(2 * input_size[1] - 1, hd))
+
+    def forward(self, x):      # (B, Hh, Ww, C)
+        B, Hh, Ww, C = x.shape
+        nh, hd = self.num_heads, C // self.num_heads
+        qkv = self.qkv(x).view(B, Hh * Ww, 3, nh, hd)
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]                 # (B, L, nh, hd)
+        # decomposed relative position bias (src/sam.py:392-426), computed from the *unscaled* q
+        rq = q.reshape(B, Hh, Ww, nh, hd)
+        rel_h = torch.einsum("bhwnc,hkc->bnhwk", rq, _rel_table(Hh, self.rel_pos_h).to(q.dtype))
+        rel_w = torch.einsum("bhwnc,wkc->bnhwk", rq, _rel_table(Ww, self.rel_pos_w).to(q.dtype))
+        bias = (rel_h[..., :, None] + rel_w[..., None, :]).reshape(B, nh, Hh * Ww, Hh * Ww)
+        o = attention(q, k, v, bias=bias)
+        return self.proj(o.reshape(B, Hh, Ww, C))
+
+
+class _SamBlock(nn.Module):
+    def __init__(self, dim, heads, window, grid):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _SamAttention(dim, heads, (window, window) if window > 0 else (grid, grid))
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _SamMlp(dim, dim * 4)
+        self.window_size = window
+
+    def forward(self, x):      # (B, H, W, C)
+        short = x
+        x = self.norm1(x)
+        ws = self.window_size
+        if ws > 0:
+            B, H, W, C = x.shape
+            ph, pw = (ws - H % ws) % ws, (ws - W % ws) % ws
+            x = F.pad(x, (0, 0, 0, pw, 0, ph))
+            Hp, Wp = H + ph, W + pw
+            x = x.view(B, Hp // ws, ws, Wp // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws, ws, C)
+            x = self.attn(x)
+            x = x.view(B, Hp // ws, Wp // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
+            x = x[:, :H, :W].contiguous()
+        else:
+            x = self.attn(x)
+        x = short + x
+        return x + self.mlp(self.norm2(x))
+
+
+class _SamPatchEmbed(nn.Module):
+    def __init__(self, patch, dim):
+        super().__init__()
+        self.patch = patch
+        self.proj = nn.Conv2d(3, dim, kernel_size=patch, stride=patch)
+
+    def forward(self, x):      # (B,3,H,W) -> (B, H/p, W/p, C)
+        B, C, H, W = x.shape
+        p = self.patch
+        gh, gw = H // p, W // p
+        x = x.view(B, C, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(B, gh, gw, C * p * p)
+        return F.linear(x, self.proj.weight.view(self.proj.weight.shape[0], -1), self.proj.bias)
+
+
+class SamImageEncoder(nn.Module):
+    """SAM ViT-B: 12 blocks, window 14 except global attention at [2,5,8,11], conv neck to 256 channels,
+    then the lossless 2x2 space-to-depth of the reference (src/sam.py:47-74) -> (B, 1024, 32, 32)."""
+
+    def __init__(self, img_size=1024, patch=16, dim=768, depth=12, heads=12, out_chans=256, window=14,
+                 global_attn_indexes=(2, 5, 8, 11)):
+        super().__init__()
+        g = img_size // patch
+        self.patch_embed = _SamPatchEmbed(patch, dim)
+        self.pos_embed = nn.Parameter(torch.zeros(1, g, g, dim))
+        self.blocks = nn.ModuleList([_SamBlock(dim, heads, 0 if i in global_attn_indexes else window, g)
+                                     for i in range(depth)])
+        self.neck = nn.Sequential(nn.Conv2d(dim, out_chans, 1, bias=False), _LayerNorm2d(out_chans),
+                                  nn.Conv2d(out_chans, out_chans, 3, padding=1, bias=False), _LayerNorm2d(out_chans))
+        self.output_dim = out_chans * 4
+
+    def forward(self, x):
+        x = self.patch_embed(x) + self.pos_embed
+        for blk in self.blocks:
+            x = blk(x)
+        x = self.neck(x.permute(0, 3, 1, 2))
+        B, C, H, W = x.shape                        # space-to-depth: each 2x2 block -> 4C channels
+        x = x.view(B, C, H // 2, 2, W // 2, 2).permute(0, 2, 4, 1, 3, 5).reshape(B, H // 2, W // 2, C * 4)
+        return x.permute(0, 3, 1, 2)
+
+
+class SamDinoSigLIPViTBackbone(nn.Module):
+    """vision.py:49-145 without the PIL/timm transform plumbing (pixel tensors come in pre-processed).
+    `towers` selects which encoders exist; the concatenation order is dino, siglip, sam (vision.py:134)."""
+
+    def __init__(self, vision_tower_path: Optional[dict] = None, default_image_size: int = 448,
+                 towers: Sequence[str] = ("dino", "siglip", "sam"), tower_kwargs: Optional[Dict[str, dict]] = None):
+        super().__init__()
+        tk = tower_kwargs or {}
+        self.towers = tuple(towers)
+        if "dino" in towers:
+            self.dino_featurizer = dinov2_large_reg4(default_image_size, **tk.get("dino", {}))
+        if "siglip" in towers:
+            self.siglip_featurizer = siglip_so400m(default_image_size, **tk.get("siglip", {}))
+        if "sam" in towers:
+            self.sam_featurizer = SamImageEncoder(**tk.get("sam", {}))
+        self.eval()
+
+    @property
+    def embed_dim(self) -> int:
+        d = 0
+        if "dino" in self.towers:
+            d += self.dino_featurizer.embed_dim
+        if "siglip" in self.towers:
+            d += self.siglip_featurizer.embed_dim
+        if "sam" in self.towers:
+            d += self.sam_featurizer.output_dim
+        return d
+
+    def forward(self, pixel_values: Dict[str, torch.Tensor]) -> torch.Tensor:
+        feats = []
+        if "dino" in self.towers:
+            feats.append(self.dino_featurizer(pixel_values["dino"]))
+        if "siglip" in self.towers:
+            feats.append(self.siglip_featurizer(pixel_values["siglip"]))
+        if "sam" in self.towers:
+            s = self.sam_featurizer(pixel_values["sam"])
+            B, C, H, W = s.shape
+            feats.append(s.view(B, C, H * W).permute(0, 2, 1))
+        return torch.cat(feats, dim=2)

@@ -31,6 +31,23 @@ _BWD_SCHEMA = ("backward(Tensor w, Tensor q, Tensor k, Tensor v, Tensor z, Tenso
                "Tensor(e!) dz, Tensor(f!) da) -> ()")
 
 
+# Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).  When
+# `EVENT_LOG` is a list, every op call appends (kind, start_event, end_event, B*T*H*64).
+EVENT_LOG = None
+
+
+def _timed(kind, elems, stream_dev, fn):
+    if EVENT_LOG is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st = torch.cuda.current_stream(stream_dev)
+    e0.record(st)
+    rc = fn()
+    e1.record(st)
+    EVENT_LOG.append((kind, e0, e1, elems))
+    return rc
+
+
 def _check_act(name, t, B, T, H):
     if t.dtype != torch.bfloat16:
         raise TypeError(f"wind_backstepping: {name} must be bfloat16, got {t.dtype}")
@@ -70,9 +87,9 @@ def _forward_hip(w, q, k, v, z, a, y, s, sa):
     lib = hip_lib.load()
     with torch.cuda.device(w.device):
         stream = torch.cuda.current_stream(w.device).cuda_stream
-        rc = lib.vrwkv_wkv7_forward_bf16(B, T, H, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(),
-                                         z.data_ptr(), a.data_ptr(), y.data_ptr(), s.data_ptr(), sa.data_ptr(),
-                                         stream)
+        rc = _timed("fwd", B * T * H * HEAD_SIZE, w.device, lambda: lib.vrwkv_wkv7_forward_bf16(
+            B, T, H, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), z.data_ptr(), a.data_ptr(),
+            y.data_ptr(), s.data_ptr(), sa.data_ptr(), stream))
     hip_lib.check(rc, "vrwkv_wkv7_forward_bf16")
 
 
@@ -87,10 +104,10 @@ def _backward_hip(w, q, k, v, z, a, dy, s, sa, dw, dq, dk, dv, dz, da):
     lib = hip_lib.load()
     with torch.cuda.device(w.device):
         stream = torch.cuda.current_stream(w.device).cuda_stream
-        rc = lib.vrwkv_wkv7_backward_bf16(B, T, H, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(),
-                                          z.data_ptr(), a.data_ptr(), dy.data_ptr(), s.data_ptr(), sa.data_ptr(),
-                                          dw.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
-                                          dz.data_ptr(), da.data_ptr(), stream)
+        rc = _timed("bwd", B * T * H * HEAD_SIZE, w.device, lambda: lib.vrwkv_wkv7_backward_bf16(
+            B, T, H, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), z.data_ptr(), a.data_ptr(),
+            dy.data_ptr(), s.data_ptr(), sa.data_ptr(), dw.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+            dv.data_ptr(), dz.data_ptr(), da.data_ptr(), stream))
     hip_lib.check(rc, "vrwkv_wkv7_backward_bf16")
 
 
