@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--img-tokens", type=int, default=576)
     ap.add_argument("--towers", default="dino,siglip")
     ap.add_argument("--grad-cp", type=int, default=0)
-    ap.add_argument("--fused", type=int, default=0)
+    ap.add_argument("--fused", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 

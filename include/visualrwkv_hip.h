@@ -57,6 +57,40 @@ int vrwkv_wkv7_set_forward_variant(int variant);
 /* backward variants: 0 = sequential VALU kernel, 1 = chunked bf16x3 MFMA kernel (the default). */
 int vrwkv_wkv7_set_backward_variant(int variant);
 
+/* ---- Fused element-wise glue of RWKV_Tmix_x070 / RWKV_CMix_x070 (VisualRWKV-v7/v7.00/src/model.py), forward and
+ * backward.  Activations are (ntok, C) bf16 contiguous (ntok = B*T), parameters C bf16, parameter gradients
+ * fp32 buffers of C floats that the kernels ADD to (zero them first).  C % 64 == 0, C <= 8192.
+ *   mix    : token-shift + M lerps, model.py:166-173 (M = 6) and :222-224 (M = 1); `mu`, `out`, `dout` are host
+ *            arrays of M device pointers; dmu is M*C floats.  Shift indexing is exact: x[t-1], zero at t = 0 of
+ *            every sample (ntok % T == 0).
+ *   decay  : w = -softplus(-(w0 + h)) - 0.5, model.py:176.
+ *   kva    : a = sigmoid(a0+al); v2 = v + (v_first - v) sigmoid(v0+vl) (layers > 0: has_vres); kk = normalize(k k_k)
+ *            per 64-channel head; k2 = k (1 + (a-1) k_a); z = -kk; b = kk a.   model.py:179-188.
+ *   post   : GroupNorm(H, C, eps)(y) + (sum_head r k r_k) v, times g.   model.py:191-194.
+ *   relusq : relu(h)^2, model.py:225.
+ */
+int vrwkv_mix_fwd_bf16(long ntok, int T, int C, int M, const void* x, const void* const* mu, void* const* out, void* stream);
+int vrwkv_mix_bwd_bf16(long ntok, int T, int C, int M, const void* x, const void* const* mu, const void* const* dout,
+                       void* dx, float* dmu, void* stream);
+int vrwkv_decay_fwd_bf16(long ntok, int C, const void* h, const void* w0, void* w, void* stream);
+int vrwkv_decay_bwd_bf16(long ntok, int C, const void* h, const void* w0, const void* dw, void* dh, float* dw0, void* stream);
+int vrwkv_kva_fwd_bf16(long ntok, int C, int has_vres, const void* k, const void* v, const void* vfirst, const void* vl,
+                       const void* al, const void* k_k, const void* k_a, const void* a0, const void* v0,
+                       void* k2, void* v2, void* z, void* b, void* stream);
+int vrwkv_kva_bwd_bf16(long ntok, int C, int has_vres, const void* k, const void* v, const void* vfirst, const void* vl,
+                       const void* al, const void* k_k, const void* k_a, const void* a0, const void* v0,
+                       const void* dk2, const void* dv2, const void* dz, const void* db,
+                       void* dk, void* dv, void* dvfirst, void* dvl, void* dal,
+                       float* dk_k, float* dk_a, float* da0, float* dv0, void* stream);
+int vrwkv_post_fwd_bf16(long ntok, int C, float eps, const void* y, const void* r, const void* k, const void* v,
+                        const void* g, const void* ln_w, const void* ln_b, const void* r_k, void* out, void* stream);
+int vrwkv_post_bwd_bf16(long ntok, int C, float eps, const void* y, const void* r, const void* k, const void* v,
+                        const void* g, const void* ln_w, const void* ln_b, const void* r_k, const void* dout,
+                        void* dy, void* dr, void* dk, void* dv, void* dg, float* dln_w, float* dln_b, float* dr_k,
+                        void* stream);
+int vrwkv_relusq_fwd_bf16(long n, const void* h, void* y, void* stream);
+int vrwkv_relusq_bwd_bf16(long n, const void* h, const void* dy, void* dh, void* stream);
+
 /* Fused AdamW step on a flat ZeRO-1 shard (replaces DeepSpeed's FusedAdam(adam_w_mode=True) that the
  * reference configures in VisualRWKV-v7/v7.00/src/model.py:410): fp32 master/m/v, bf16 gradient in, bf16
  * parameter out, gradient pre-scaled by grad_scale (clip coefficient / world size), bias correction for

@@ -1,0 +1,147 @@
+"""Fused element-wise HIP kernels (csrc/tmix_fused.hip) against an fp32 torch statement of the reference
+formulas (src/model.py:166-194,222-225) evaluated on the same bf16 inputs; outputs/gradients compared after
+one rounding to bf16 (rel-RMS <= 1e-3; 2e-3 for the atomically accumulated parameter gradients).
+Token-shift indexing is checked bit-exactly."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle.wkv7_oracle import rel_rms
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).bfloat16().cuda()
+
+
+def _ref_grads(fn, inputs, gouts):
+    """fn on fp32 copies -> outputs, grads (fp32)."""
+    xs = [x.detach().float().requires_grad_(True) for x in inputs]
+    outs = fn(*xs)
+    outs = outs if isinstance(outs, tuple) else (outs,)
+    torch.autograd.backward(outs, [g.float() for g in gouts])
+    return outs, [x.grad for x in xs]
+
+
+def _check(mine, ref, tol=TOL, names=None):
+    for i, (a, b) in enumerate(zip(mine, ref)):
+        e = rel_rms(a.float().cpu(), b.detach().bfloat16().float().cpu())
+        assert e < tol, (names[i] if names else i, e)
+
+
+@pytest.mark.parametrize("B,T,C,M", [(2, 5, 128, 6), (3, 33, 768, 6), (1, 40, 2048, 1)])
+def test_mix(B, T, C, M):
+    from visualrwkv_amd import fused
+    x = _rnd(B, T, C, seed=1)
+    mus = [torch.rand(1, 1, C, generator=torch.Generator().manual_seed(10 + i)).bfloat16().cuda() for i in range(M)]
+    gouts = [_rnd(B, T, C, seed=20 + i) for i in range(M)]
+
+    def ref(x, *mus):
+        xx = F.pad(x, (0, 0, 1, -1)) - x
+        return tuple(x + xx * m for m in mus)
+
+    xs = [x.clone().requires_grad_(True)] + [m.clone().requires_grad_(True) for m in mus]
+    outs = fused.mix(*xs)
+    torch.autograd.backward(outs, gouts)
+    r_outs, r_grads = _ref_grads(ref, [x] + mus, gouts)
+    _check(outs, r_outs)
+    _check([xs[0].grad], [r_grads[0]])
+    _check([t.grad for t in xs[1:]], r_grads[1:], tol=2e-3)
+    # exact shift indexing: integer-valued x (all fp32 arithmetic exact) and mu = 1 give exactly the previous
+    # token, and exactly 0 at t = 0 of every sample
+    xi = torch.randint(-8, 9, (B, T, C), generator=torch.Generator().manual_seed(3)).bfloat16().cuda()
+    ones = [torch.ones(1, 1, C, dtype=torch.bfloat16, device="cuda") for _ in range(M)]
+    for o in fused.mix(xi, *ones):
+        assert torch.equal(o[:, 1:], xi[:, :-1]) and torch.equal(o[:, 0], torch.zeros_like(o[:, 0]))
+
+
+def test_decay():
+    from visualrwkv_amd import fused
+    h = _rnd(2, 17, 256, scale=3.0, seed=3)
+    w0 = _rnd(1, 1, 256, scale=2.0, seed=4)
+    g = _rnd(2, 17, 256, seed=5)
+    ref = lambda h, w0: -F.softplus(-(w0 + h)) - 0.5
+    hh, ww = h.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+    w = fused.decay(hh, ww)
+    w.backward(g)
+    (rw,), (rdh, rdw0) = _ref_grads(ref, [h, w0], [g])
+    _check([w, hh.grad], [rw, rdh])
+    _check([ww.grad], [rdw0], tol=2e-3)
+    assert float(w.float().max()) <= -0.5
+
+
+@pytest.mark.parametrize("has_vres", [False, True])
+def test_kva(has_vres):
+    from visualrwkv_amd import fused
+    B, T, C, H = 2, 9, 256, 4
+    k, v, vf, vl, al = [_rnd(B, T, C, seed=30 + i) for i in range(5)]
+    k_k, k_a, a0, v0 = [_rnd(1, 1, C, scale=0.5, seed=40 + i) for i in range(4)]
+    gouts = [_rnd(B, T, C, seed=50 + i) for i in range(4)]
+
+    def ref(k, v, vf, vl, al, k_k, k_a, a0, v0):
+        a = torch.sigmoid(a0 + al)
+        v2 = v + (vf - v) * torch.sigmoid(v0 + vl)
+        kk = F.normalize((k * k_k).view(B, T, H, -1), dim=-1, p=2.0).view(B, T, C)
+        k2 = k * (1 + (a - 1) * k_a)
+        return (k2, v2, -kk, kk * a) if has_vres else (k2, -kk, kk * a)
+
+    ins = [k, v, vf, vl, al, k_k, k_a, a0, v0]
+    xs = [t.clone().requires_grad_(True) for t in ins]
+    if has_vres:
+        outs = fused.kva(*xs)
+        go = gouts
+    else:
+        outs = fused.kva(xs[0], None, None, None, xs[4], xs[5], xs[6], xs[7], None)
+        go = [gouts[0], gouts[2], gouts[3]]
+    torch.autograd.backward(outs, go)
+    r_outs, r_grads = _ref_grads(ref, ins, go)
+    _check(outs, r_outs)
+    idx = [0, 1, 2, 3, 4] if has_vres else [0, 4]
+    _check([xs[i].grad for i in idx], [r_grads[i] for i in idx], names=idx)
+    pidx = [5, 6, 7, 8] if has_vres else [5, 6, 7]
+    _check([xs[i].grad for i in pidx], [r_grads[i] for i in pidx], tol=2e-3, names=pidx)
+
+
+def test_post():
+    from visualrwkv_amd import fused
+    B, T, C, H = 2, 11, 256, 4
+    y, r, k, v, g = [_rnd(B, T, C, seed=60 + i) for i in range(5)]
+    ln_w, ln_b = _rnd(C, seed=70) * 0.5 + 1, _rnd(C, scale=0.1, seed=71)
+    r_k = _rnd(H, 64, scale=0.3, seed=72)
+    go = _rnd(B, T, C, seed=73)
+    eps = 64e-5
+
+    def ref(y, r, k, v, g, ln_w, ln_b, r_k):
+        x = F.group_norm(y.view(B * T, C), H, ln_w, ln_b, eps).view(B, T, C)
+        x = x + ((r.view(B, T, H, -1) * k.view(B, T, H, -1) * r_k).sum(dim=-1, keepdim=True) * v.view(B, T, H, -1)).view(B, T, C)
+        return x * g
+
+    ins = [y, r, k, v, g, ln_w, ln_b, r_k]
+    xs = [t.clone().requires_grad_(True) for t in ins]
+    out = fused.post(*xs, eps)
+    out.backward(go)
+    (r_out,), r_grads = _ref_grads(ref, ins, [go])
+    _check([out], [r_out])
+    _check([t.grad for t in xs[:5]], r_grads[:5], names=list("yrkvg"))
+    _check([t.grad for t in xs[5:]], r_grads[5:], tol=2e-3, names=["ln_w", "ln_b", "r_k"])
+
+
+def test_relu_sq():
+    from visualrwkv_amd import fused
+    h = _rnd(3, 7, 512, seed=80)
+    g = _rnd(3, 7, 512, seed=81)
+    hh = h.clone().requires_grad_(True)
+    y = fused.relu_sq(hh)
+    y.backward(g)
+    (ry,), (rdh,) = _ref_grads(lambda h: torch.relu(h) ** 2, [h], [g])
+    _check([y, hh.grad], [ry, rdh])
+
+
+def test_fused_rejects_wrong_inputs():
+    from visualrwkv_amd import fused
+    x = torch.randn(1, 4, 128, device="cuda")          # fp32: must raise, not fall back
+    with pytest.raises(ValueError):
+        fused.relu_sq(x)

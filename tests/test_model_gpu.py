@@ -31,7 +31,7 @@ def _lm(gold, fused=False, grad_cp=0):
     return m.bfloat16().cuda()
 
 
-@pytest.mark.parametrize("fused", [False])
+@pytest.mark.parametrize("fused", [False, True])
 def test_modules_match_reference(gold, fused):
     m = _lm(gold, fused)
     g = gold["mods"]
@@ -48,7 +48,7 @@ def test_modules_match_reference(gold, fused):
     assert rel_rms(b1.float().cpu(), g["block1_y"].float()) < TOL
 
 
-@pytest.mark.parametrize("fused,grad_cp", [(False, 0), (False, 1)])
+@pytest.mark.parametrize("fused,grad_cp", [(False, 0), (False, 1), (True, 0), (True, 1)])
 def test_lm_forward_backward_with_padding(gold, fused, grad_cp):
     """RWKV.forward on T=37 (left-padded to 48 with emb(261), model.py:286-312) + backward."""
     m = _lm(gold, fused, grad_cp)
@@ -70,7 +70,7 @@ def test_full_visual_step_runs_and_learns():
     from visualrwkv_amd.visual import VisualRWKV
     args = SimpleNamespace(n_embd=128, n_layer=2, dim_att=128, head_size_a=64, head_size_divisor=8, vocab_size=65536,
                            dropout=0, grad_cp=0, ctx_len=48, num_token_per_image=16, vision_towers=("dino", "siglip", "sam"),
-                           vision_image_size=56, load_model="", proj_type="mlp", weight_decay=0.0, fused=False,
+                           vision_image_size=56, load_model="", proj_type="mlp", weight_decay=0.0, fused=True,
                            vision_tower_kwargs={"dino": dict(depth=3, dim=64, heads=1), "siglip": dict(depth=3, dim=64, heads=1, mlp_hidden=96),
                                                 "sam": dict(img_size=128, dim=64, depth=3, heads=1, out_chans=16, window=3, global_attn_indexes=(2,))})
     torch.manual_seed(0)

@@ -1,0 +1,245 @@
+"""Fused HIP implementations of the element-wise glue of RWKV_Tmix_x070 / RWKV_CMix_x070.
+
+Enabled per model with `args.fused = True` (rwkv7.py dispatches here for CUDA tensors).  Each autograd
+Function below is one forward kernel and one backward kernel of csrc/tmix_fused.hip; the dense projections
+stay hipBLASLt GEMMs (plain `F.linear` / `@`).  There is no fallback: tensors must be bf16, contiguous, on an
+MI355X -- anything else raises.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import hip_lib
+from .wkv7 import RUN_CUDA_RWKV7g
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()):
+            raise ValueError("fused RWKV-7 kernels need contiguous bf16 tensors on the GPU "
+                             f"(got {t.dtype}, cuda={t.is_cuda}, contiguous={t.is_contiguous()})")
+
+
+def _ptr_array(ts):
+    return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else 0
+
+
+class _Mix(torch.autograd.Function):
+    """token-shift + M lerps:  out_m = x + (shift(x) - x) * mu_m."""
+
+    @staticmethod
+    def forward(ctx, x, *mus):
+        B, T, C = x.shape
+        x = x.contiguous()
+        mus_c = [m.reshape(C).contiguous() for m in mus]
+        _chk(x, *mus_c)
+        outs = [torch.empty_like(x) for _ in mus]
+        rc = hip_lib.load().vrwkv_mix_fwd_bf16(B * T, T, C, len(mus), x.data_ptr(), _ptr_array(mus_c), _ptr_array(outs), _stream(x))
+        hip_lib.check(rc, "vrwkv_mix_fwd_bf16")
+        ctx.save_for_backward(x, *mus_c)
+        ctx.mu_shapes = [m.shape for m in mus]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        x, *mus_c = ctx.saved_tensors
+        B, T, C = x.shape
+        douts = [d.contiguous() for d in douts]
+        _chk(*douts)
+        dx = torch.empty_like(x)
+        dmu = torch.zeros(len(mus_c), C, dtype=torch.float32, device=x.device)
+        rc = hip_lib.load().vrwkv_mix_bwd_bf16(B * T, T, C, len(mus_c), x.data_ptr(), _ptr_array(mus_c), _ptr_array(douts),
+                                               dx.data_ptr(), dmu.data_ptr(), _stream(x))
+        hip_lib.check(rc, "vrwkv_mix_bwd_bf16")
+        dmu = dmu.to(x.dtype)
+        return (dx, *[dmu[i].view(s) for i, s in enumerate(ctx.mu_shapes)])
+
+
+class _Decay(torch.autograd.Function):
+    """w = -softplus(-(w0 + h)) - 0.5"""
+
+    @staticmethod
+    def forward(ctx, h, w0):
+        h = h.contiguous()
+        C = h.shape[-1]
+        w0c = w0.reshape(C).contiguous()
+        _chk(h, w0c)
+        w = torch.empty_like(h)
+        rc = hip_lib.load().vrwkv_decay_fwd_bf16(h.numel() // C, C, h.data_ptr(), w0c.data_ptr(), w.data_ptr(), _stream(h))
+        hip_lib.check(rc, "vrwkv_decay_fwd_bf16")
+        ctx.save_for_backward(h, w0c)
+        ctx.w0_shape = w0.shape
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        h, w0c = ctx.saved_tensors
+        C = h.shape[-1]
+        dw = dw.contiguous()
+        _chk(dw)
+        dh = torch.empty_like(h)
+        dw0 = torch.zeros(C, dtype=torch.float32, device=h.device)
+        rc = hip_lib.load().vrwkv_decay_bwd_bf16(h.numel() // C, C, h.data_ptr(), w0c.data_ptr(), dw.data_ptr(), dh.data_ptr(),
+                                                 dw0.data_ptr(), _stream(h))
+        hip_lib.check(rc, "vrwkv_decay_bwd_bf16")
+        return dh, dw0.to(h.dtype).view(ctx.w0_shape)
+
+
+class _Kva(torch.autograd.Function):
+    """(k, v, v_first, vl, al; k_k, k_a, a0, v0) -> (k2, v2, z, b); v/v_first/vl/v0 are None for layer 0."""
+
+    @staticmethod
+    def forward(ctx, k, v, v_first, vl, al, k_k, k_a, a0, v0):
+        has = v is not None
+        k, al = k.contiguous(), al.contiguous()
+        C = k.shape[-1]
+        ntok = k.numel() // C
+        if has:
+            v, v_first, vl = v.contiguous(), v_first.contiguous(), vl.contiguous()
+        pk, pa, p0 = k_k.reshape(C).contiguous(), k_a.reshape(C).contiguous(), a0.reshape(C).contiguous()
+        pv = v0.reshape(C).contiguous() if has else None
+        _chk(k, al, v, v_first, vl, pk, pa, p0, pv)
+        k2, z, b = torch.empty_like(k), torch.empty_like(k), torch.empty_like(k)
+        v2 = torch.empty_like(k) if has else None
+        rc = hip_lib.load().vrwkv_kva_fwd_bf16(ntok, C, int(has), k.data_ptr(), _p(v), _p(v_first), _p(vl), al.data_ptr(),
+                                               pk.data_ptr(), pa.data_ptr(), p0.data_ptr(), _p(pv),
+                                               k2.data_ptr(), _p(v2), z.data_ptr(), b.data_ptr(), _stream(k))
+        hip_lib.check(rc, "vrwkv_kva_fwd_bf16")
+        ctx.has = has
+        ctx.shapes = (k_k.shape, k_a.shape, a0.shape, v0.shape if has else None)
+        ctx.save_for_backward(k, v, v_first, vl, al, pk, pa, p0, pv)
+        if has:
+            return k2, v2, z, b
+        return k2, z, b
+
+    @staticmethod
+    def backward(ctx, *grads):
+        k, v, v_first, vl, al, pk, pa, p0, pv = ctx.saved_tensors
+        has = ctx.has
+        if has:
+            dk2, dv2, dz, db = [g.contiguous() for g in grads]
+        else:
+            dk2, dz, db = [g.contiguous() for g in grads]
+            dv2 = None
+        _chk(dk2, dv2, dz, db)
+        C = k.shape[-1]
+        ntok = k.numel() // C
+        dk, dal = torch.empty_like(k), torch.empty_like(k)
+        dv = torch.empty_like(k) if has else None
+        dvf = torch.empty_like(k) if has else None
+        dvl = torch.empty_like(k) if has else None
+        pg = torch.zeros(4, C, dtype=torch.float32, device=k.device)
+        rc = hip_lib.load().vrwkv_kva_bwd_bf16(ntok, C, int(has), k.data_ptr(), _p(v), _p(v_first), _p(vl), al.data_ptr(),
+                                               pk.data_ptr(), pa.data_ptr(), p0.data_ptr(), _p(pv),
+                                               dk2.data_ptr(), _p(dv2), dz.data_ptr(), db.data_ptr(),
+                                               dk.data_ptr(), _p(dv), _p(dvf), _p(dvl), dal.data_ptr(),
+                                               pg[0].data_ptr(), pg[1].data_ptr(), pg[2].data_ptr(), pg[3].data_ptr() if has else 0, _stream(k))
+        hip_lib.check(rc, "vrwkv_kva_bwd_bf16")
+        pgb = pg.to(k.dtype)
+        s = ctx.shapes
+        return (dk, dv, dvf, dvl, dal, pgb[0].view(s[0]), pgb[1].view(s[1]), pgb[2].view(s[2]), pgb[3].view(s[3]) if has else None)
+
+
+class _Post(torch.autograd.Function):
+    """out = (GroupNorm(y) + (sum_head r*k*r_k) * v) * g"""
+
+    @staticmethod
+    def forward(ctx, y, r, k, v, g, ln_w, ln_b, r_k, eps):
+        y, r, k, v, g = [t.contiguous() for t in (y, r, k, v, g)]
+        C = y.shape[-1]
+        lw, lb, rk = ln_w.contiguous(), ln_b.contiguous(), r_k.reshape(C).contiguous()
+        _chk(y, r, k, v, g, lw, lb, rk)
+        out = torch.empty_like(y)
+        rc = hip_lib.load().vrwkv_post_fwd_bf16(y.numel() // C, C, float(eps), y.data_ptr(), r.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                                g.data_ptr(), lw.data_ptr(), lb.data_ptr(), rk.data_ptr(), out.data_ptr(), _stream(y))
+        hip_lib.check(rc, "vrwkv_post_fwd_bf16")
+        ctx.save_for_backward(y, r, k, v, g, lw, lb, rk)
+        ctx.eps = float(eps)
+        ctx.rk_shape = r_k.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, r, k, v, g, lw, lb, rk = ctx.saved_tensors
+        dout = dout.contiguous()
+        _chk(dout)
+        C = y.shape[-1]
+        dy, dr, dk, dv, dg = [torch.empty_like(y) for _ in range(5)]
+        pg = torch.zeros(3, C, dtype=torch.float32, device=y.device)
+        rc = hip_lib.load().vrwkv_post_bwd_bf16(y.numel() // C, C, ctx.eps, y.data_ptr(), r.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                                g.data_ptr(), lw.data_ptr(), lb.data_ptr(), rk.data_ptr(), dout.data_ptr(),
+                                                dy.data_ptr(), dr.data_ptr(), dk.data_ptr(), dv.data_ptr(), dg.data_ptr(),
+                                                pg[0].data_ptr(), pg[1].data_ptr(), pg[2].data_ptr(), _stream(y))
+        hip_lib.check(rc, "vrwkv_post_bwd_bf16")
+        pgb = pg.to(y.dtype)
+        return dy, dr, dk, dv, dg, pgb[0], pgb[1], pgb[2].view(ctx.rk_shape), None
+
+
+class _ReluSq(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h):
+        h = h.contiguous()
+        _chk(h)
+        y = torch.empty_like(h)
+        rc = hip_lib.load().vrwkv_relusq_fwd_bf16(h.numel(), h.data_ptr(), y.data_ptr(), _stream(h))
+        hip_lib.check(rc, "vrwkv_relusq_fwd_bf16")
+        ctx.save_for_backward(h)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (h,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        _chk(dy)
+        dh = torch.empty_like(h)
+        rc = hip_lib.load().vrwkv_relusq_bwd_bf16(h.numel(), h.data_ptr(), dy.data_ptr(), dh.data_ptr(), _stream(h))
+        hip_lib.check(rc, "vrwkv_relusq_bwd_bf16")
+        return dh
+
+
+mix = _Mix.apply
+decay = _Decay.apply
+kva = _Kva.apply
+post = _Post.apply
+relu_sq = _ReluSq.apply
+
+
+def tmix_forward(m, x, v_first):
+    """RWKV_Tmix_x070.forward (src/model.py:163-195) with the glue fused; `m` is the module."""
+    B, T, C = x.shape
+    xr, xw, xk, xv, xa, xg = mix(x, m.x_r, m.x_w, m.x_k, m.x_v, m.x_a, m.x_g)
+    r = m.receptance(xr)
+    w = decay(torch.tanh(xw @ m.w1) @ m.w2, m.w0)
+    k = m.key(xk)
+    v = m.value(xv)
+    al = (xa @ m.a1) @ m.a2
+    g = torch.sigmoid(xg @ m.g1) @ m.g2
+    if m.layer_id == 0:
+        v_first = v
+        k2, z, b = kva(k, None, None, None, al, m.k_k, m.k_a, m.a0, None)
+        v2 = v
+    else:
+        vl = (xv @ m.v1) @ m.v2
+        k2, v2, z, b = kva(k, v, v_first, vl, al, m.k_k, m.k_a, m.a0, m.v0)
+    y = RUN_CUDA_RWKV7g(r, w, k2, v2, z, b)
+    y = post(y, r, k2, v2, g, m.ln_x.weight, m.ln_x.bias, m.r_k, m.ln_x.eps)
+    return m.output(y), v_first
+
+
+def cmix_forward(m, x):
+    """RWKV_CMix_x070.forward (src/model.py:221-227)."""
+    (k,) = mix(x, m.x_k)
+    return m.value(relu_sq(m.key(k)))
