@@ -58,8 +58,10 @@ int vrwkv_wkv7_set_forward_variant(int variant);
 int vrwkv_wkv7_set_backward_variant(int variant);
 
 /* ---- Fused element-wise glue of RWKV_Tmix_x070 / RWKV_CMix_x070 (VisualRWKV-v7/v7.00/src/model.py), forward and
- * backward.  Activations are (ntok, C) bf16 contiguous (ntok = B*T), parameters C bf16, parameter gradients
- * fp32 buffers of C floats that the kernels ADD to (zero them first).  C % 64 == 0, C <= 8192.
+ * backward.  Activations are (ntok, C) bf16 contiguous (ntok = B*T), parameters C bf16.  Parameter gradients
+ * are written (not accumulated) as fp32; the backward entry points need a scratch buffer `ws` of
+ * vrwkv_param_grad_ws_floats(ntok, C, nvec) floats (nvec = number of C-sized gradient vectors: M for mix, 1 for
+ * decay, 4 for kva, 3 for post) for the per-workgroup partial sums.  C % 64 == 0, C <= 8192.
  *   mix    : token-shift + M lerps, model.py:166-173 (M = 6) and :222-224 (M = 1); `mu`, `out`, `dout` are host
  *            arrays of M device pointers; dmu is M*C floats.  Shift indexing is exact: x[t-1], zero at t = 0 of
  *            every sample (ntok % T == 0).
@@ -70,10 +72,12 @@ int vrwkv_wkv7_set_backward_variant(int variant);
  *   relusq : relu(h)^2, model.py:225.
  */
 int vrwkv_mix_fwd_bf16(long ntok, int T, int C, int M, const void* x, const void* const* mu, void* const* out, void* stream);
+long vrwkv_param_grad_ws_floats(long ntok, int C, int nvec);
 int vrwkv_mix_bwd_bf16(long ntok, int T, int C, int M, const void* x, const void* const* mu, const void* const* dout,
-                       void* dx, float* dmu, void* stream);
+                       void* dx, float* dmu, float* ws, void* stream);
 int vrwkv_decay_fwd_bf16(long ntok, int C, const void* h, const void* w0, void* w, void* stream);
-int vrwkv_decay_bwd_bf16(long ntok, int C, const void* h, const void* w0, const void* dw, void* dh, float* dw0, void* stream);
+int vrwkv_decay_bwd_bf16(long ntok, int C, const void* h, const void* w0, const void* dw, void* dh, float* dw0, float* ws,
+                         void* stream);
 int vrwkv_kva_fwd_bf16(long ntok, int C, int has_vres, const void* k, const void* v, const void* vfirst, const void* vl,
                        const void* al, const void* k_k, const void* k_a, const void* a0, const void* v0,
                        void* k2, void* v2, void* z, void* b, void* stream);
@@ -81,13 +85,13 @@ int vrwkv_kva_bwd_bf16(long ntok, int C, int has_vres, const void* k, const void
                        const void* al, const void* k_k, const void* k_a, const void* a0, const void* v0,
                        const void* dk2, const void* dv2, const void* dz, const void* db,
                        void* dk, void* dv, void* dvfirst, void* dvl, void* dal,
-                       float* dk_k, float* dk_a, float* da0, float* dv0, void* stream);
+                       float* dparams /* 4*C: dk_k dk_a da0 dv0 */, float* ws, void* stream);
 int vrwkv_post_fwd_bf16(long ntok, int C, float eps, const void* y, const void* r, const void* k, const void* v,
                         const void* g, const void* ln_w, const void* ln_b, const void* r_k, void* out, void* stream);
 int vrwkv_post_bwd_bf16(long ntok, int C, float eps, const void* y, const void* r, const void* k, const void* v,
                         const void* g, const void* ln_w, const void* ln_b, const void* r_k, const void* dout,
-                        void* dy, void* dr, void* dk, void* dv, void* dg, float* dln_w, float* dln_b, float* dr_k,
-                        void* stream);
+                        void* dy, void* dr, void* dk, void* dv, void* dg, float* dparams /* 3*C: dln_w dln_b dr_k */,
+                        float* ws, void* stream);
 int vrwkv_relusq_fwd_bf16(long n, const void* h, void* y, void* stream);
 int vrwkv_relusq_bwd_bf16(long n, const void* h, const void* dy, void* dh, void* stream);
 

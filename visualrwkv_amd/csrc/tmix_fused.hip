@@ -6,8 +6,10 @@
 // relu^2); on MI355X that is pure HBM traffic (measured: 242 ms of a 510 ms training step).  Here each group is
 // one pass: a workgroup owns TPB consecutive tokens, a thread owns 8 consecutive channels (16-byte bf16
 // accesses; a 64-channel head = 8 adjacent lanes, reduced with DPP), arithmetic in fp32, one rounding to bf16
-// at the end.  Per-channel parameter gradients are accumulated in registers over the workgroup's tokens and
-// added to fp32 buffers with one atomic per channel per workgroup.
+// at the end.  Per-channel parameter gradients are accumulated in registers over the workgroup's tokens, written
+// as one fp32 partial row per workgroup and summed by a second tiny kernel (no atomics: same-address fp32
+// atomics from ~1300 workgroups serialised and made the backward kernels 3-4x slower than HBM-bound;
+// this is also deterministic).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/visualrwkv_hip.h"
@@ -32,9 +34,24 @@ DEVFN void st8f(uint16_t* p, const V8& v) {
                                               cvt_pk_bf16(v.f[4], v.f[5]), cvt_pk_bf16(v.f[6], v.f[7]));
 }
 DEVFN V8 zero8() { V8 r; for (int e = 0; e < 8; ++e) r.f[e] = 0.f; return r; }
-DEVFN void atomic8(float* dst, const V8& v) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(dst + e, v.f[e]);
+// per-workgroup partial of a column sum: part[blockIdx.x][vec][c]
+DEVFN void put_partial(float* part, int nvec, int vec, int C, int c0, const V8& v) {
+    float* dst = part + ((size_t)blockIdx.x * nvec + vec) * C + c0;
+    *reinterpret_cast<float4*>(dst) = make_float4(v.f[0], v.f[1], v.f[2], v.f[3]);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(v.f[4], v.f[5], v.f[6], v.f[7]);
+}
+// out[j] = sum_g part[g][j]
+__global__ __launch_bounds__(256) void colsum_kernel(int G, long width, const float* __restrict__ part, float* __restrict__ out) {
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= width) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int g = 0;
+    for (; g + 3 < G; g += 4) {
+        a0 += part[(size_t)g * width + j]; a1 += part[(size_t)(g + 1) * width + j];
+        a2 += part[(size_t)(g + 2) * width + j]; a3 += part[(size_t)(g + 3) * width + j];
+    }
+    for (; g < G; ++g) a0 += part[(size_t)g * width + j];
+    out[j] = (a0 + a1) + (a2 + a3);
 }
 DEVFN float sigmoidf_(float x) { return 1.f / (1.f + fast_exp(-x)); }
 
@@ -48,10 +65,8 @@ __global__ void mix_fwd_kernel(long ntok, int T, int C, const uint16_t* __restri
     V8 m[M];
 #pragma unroll
     for (int i = 0; i < M; ++i) m[i] = ld8f(mu.p[i] + c0);
-    const long n0 = (long)blockIdx.x * TPB;
-    for (int i = 0; i < TPB; ++i) {
-        const long n = n0 + i;
-        if (n >= ntok) break;
+    for (long nb = (long)blockIdx.x * TPB; nb < ntok; nb += (long)gridDim.x * TPB)
+    for (long n = nb; n < nb + TPB && n < ntok; ++n) {
         const V8 xv = ld8f(x + n * C + c0);
         V8 xx;
         if (n % T != 0) {
@@ -79,10 +94,8 @@ __global__ void mix_bwd_kernel(long ntok, int T, int C, const uint16_t* __restri
     V8 m[M], gm[M];
 #pragma unroll
     for (int i = 0; i < M; ++i) { m[i] = ld8f(mu.p[i] + c0); gm[i] = zero8(); }
-    const long n0 = (long)blockIdx.x * TPB;
-    for (int i = 0; i < TPB; ++i) {
-        const long n = n0 + i;
-        if (n >= ntok) break;
+    for (long nb = (long)blockIdx.x * TPB; nb < ntok; nb += (long)gridDim.x * TPB)
+    for (long n = nb; n < nb + TPB && n < ntok; ++n) {
         const int t = (int)(n % T);
         const V8 xv = ld8f(x + n * C + c0);
         V8 xx, acc = zero8();
@@ -112,7 +125,7 @@ __global__ void mix_bwd_kernel(long ntok, int T, int C, const uint16_t* __restri
         st8f(dx + n * C + c0, acc);
     }
 #pragma unroll
-    for (int j = 0; j < M; ++j) atomic8(dmu + (long)j * C + c0, gm[j]);
+    for (int j = 0; j < M; ++j) put_partial(dmu, M, j, C, c0, gm[j]);
 }
 
 // ---------------------------------------------------------------------------------------------- F2: decay soft-clamp
@@ -121,10 +134,8 @@ __global__ void decay_fwd_kernel(long ntok, int C, const uint16_t* __restrict__ 
                                  uint16_t* __restrict__ w) {
     const int c0 = threadIdx.x * 8;
     const V8 b = ld8f(w0 + c0);
-    const long n0 = (long)blockIdx.x * TPB;
-    for (int i = 0; i < TPB; ++i) {
-        const long n = n0 + i;
-        if (n >= ntok) break;
+    for (long nb = (long)blockIdx.x * TPB; nb < ntok; nb += (long)gridDim.x * TPB)
+    for (long n = nb; n < nb + TPB && n < ntok; ++n) {
         const V8 hv = ld8f(h + n * C + c0);
         V8 o;
 #pragma unroll
@@ -141,10 +152,8 @@ __global__ void decay_bwd_kernel(long ntok, int C, const uint16_t* __restrict__ 
     const int c0 = threadIdx.x * 8;
     const V8 b = ld8f(w0 + c0);
     V8 g0 = zero8();
-    const long n0 = (long)blockIdx.x * TPB;
-    for (int i = 0; i < TPB; ++i) {
-        const long n = n0 + i;
-        if (n >= ntok) break;
+    for (long nb = (long)blockIdx.x * TPB; nb < ntok; nb += (long)gridDim.x * TPB)
+    for (long n = nb; n < nb + TPB && n < ntok; ++n) {
         const V8 hv = ld8f(h + n * C + c0), d = ld8f(dw + n * C + c0);
         V8 o;
 #pragma unroll
@@ -154,7 +163,7 @@ __global__ void decay_bwd_kernel(long ntok, int C, const uint16_t* __restrict__ 
         }
         st8f(dh + n * C + c0, o);
     }
-    atomic8(dw0 + c0, g0);
+    put_partial(dw0, 1, 0, C, c0, g0);
 }
 
 // ---------------------------------------------------------------------------------------------- F3: k / v / a glue
@@ -169,10 +178,8 @@ __global__ void kva_fwd_kernel(KvaFwd p) {
     const V8 kk_p = ld8f(p.k_k + c0), ka_p = ld8f(p.k_a + c0), a0 = ld8f(p.a0 + c0);
     V8 v0 = zero8();
     if (p.has_vres) v0 = ld8f(p.v0 + c0);
-    const long n0 = (long)blockIdx.x * TPB;
-    for (int i = 0; i < TPB; ++i) {
-        const long n = n0 + i;
-        if (n >= p.ntok) break;
+    for (long nb = (long)blockIdx.x * TPB; nb < p.ntok; nb += (long)gridDim.x * TPB)
+    for (long n = nb; n < nb + TPB && n < p.ntok; ++n) {
         const long o = n * C + c0;
         const V8 k = ld8f(p.k + o), al = ld8f(p.al + o);
         V8 a, kk, k2, z, b;
@@ -203,7 +210,7 @@ struct KvaBwd {
     const uint16_t *k, *v, *vfirst, *vl, *al, *k_k, *k_a, *a0, *v0;
     const uint16_t *dk2, *dv2, *dz, *db;               // incoming
     uint16_t *dk, *dv, *dvfirst, *dvl, *dal;           // outgoing
-    float *dk_k, *dk_a, *da0, *dv0;                    // parameter gradients (fp32, atomics)
+    float* part;                                       // [grid][4][C] partials of dk_k dk_a da0 dv0
 };
 __global__ void kva_bwd_kernel(KvaBwd p) {
     const int c0 = threadIdx.x * 8, C = p.C;
@@ -211,10 +218,8 @@ __global__ void kva_bwd_kernel(KvaBwd p) {
     V8 v0 = zero8();
     if (p.has_vres) v0 = ld8f(p.v0 + c0);
     V8 g_kk = zero8(), g_ka = zero8(), g_a0 = zero8(), g_v0 = zero8();
-    const long n0 = (long)blockIdx.x * TPB;
-    for (int i = 0; i < TPB; ++i) {
-        const long n = n0 + i;
-        if (n >= p.ntok) break;
+    for (long nb = (long)blockIdx.x * TPB; nb < p.ntok; nb += (long)gridDim.x * TPB)
+    for (long n = nb; n < nb + TPB && n < p.ntok; ++n) {
         const long o = n * C + c0;
         const V8 k = ld8f(p.k + o), al = ld8f(p.al + o);
         const V8 dk2 = ld8f(p.dk2 + o), dz = ld8f(p.dz + o), db = ld8f(p.db + o);
@@ -262,8 +267,8 @@ __global__ void kva_bwd_kernel(KvaBwd p) {
             st8f(p.dv + o, dv); st8f(p.dvfirst + o, dvf); st8f(p.dvl + o, dvl);
         }
     }
-    atomic8(p.dk_k + c0, g_kk); atomic8(p.dk_a + c0, g_ka); atomic8(p.da0 + c0, g_a0);
-    if (p.has_vres) atomic8(p.dv0 + c0, g_v0);
+    put_partial(p.part, 4, 0, C, c0, g_kk); put_partial(p.part, 4, 1, C, c0, g_ka);
+    put_partial(p.part, 4, 2, C, c0, g_a0); put_partial(p.part, 4, 3, C, c0, g_v0);
 }
 
 // ---------------------------------------------------------------------------------------------- F4: GroupNorm + bonus + gate
@@ -275,10 +280,8 @@ struct PostFwd {
 __global__ void post_fwd_kernel(PostFwd p) {
     const int c0 = threadIdx.x * 8, C = p.C;
     const V8 lw = ld8f(p.ln_w + c0), lb = ld8f(p.ln_b + c0), rk = ld8f(p.r_k + c0);
-    const long n0 = (long)blockIdx.x * TPB;
-    for (int i = 0; i < TPB; ++i) {
-        const long n = n0 + i;
-        if (n >= p.ntok) break;
+    for (long nb = (long)blockIdx.x * TPB; nb < p.ntok; nb += (long)gridDim.x * TPB)
+    for (long n = nb; n < nb + TPB && n < p.ntok; ++n) {
         const long o = n * C + c0;
         const V8 y = ld8f(p.y + o), r = ld8f(p.r + o), k = ld8f(p.k + o), v = ld8f(p.v + o), g = ld8f(p.g + o);
         float s1 = 0.f, sb = 0.f;
@@ -304,16 +307,14 @@ struct PostBwd {
     long ntok; int C; float eps;
     const uint16_t *y, *r, *k, *v, *g, *ln_w, *ln_b, *r_k, *dout;
     uint16_t *dy, *dr, *dk, *dv, *dg;
-    float *dln_w, *dln_b, *dr_k;
+    float* part;                                       // [grid][3][C] partials of dln_w dln_b dr_k
 };
 __global__ void post_bwd_kernel(PostBwd p) {
     const int c0 = threadIdx.x * 8, C = p.C;
     const V8 lw = ld8f(p.ln_w + c0), lb = ld8f(p.ln_b + c0), rk = ld8f(p.r_k + c0);
     V8 g_w = zero8(), g_b = zero8(), g_rk = zero8();
-    const long n0 = (long)blockIdx.x * TPB;
-    for (int i = 0; i < TPB; ++i) {
-        const long n = n0 + i;
-        if (n >= p.ntok) break;
+    for (long nb = (long)blockIdx.x * TPB; nb < p.ntok; nb += (long)gridDim.x * TPB)
+    for (long n = nb; n < nb + TPB && n < p.ntok; ++n) {
         const long o = n * C + c0;
         const V8 y = ld8f(p.y + o), r = ld8f(p.r + o), k = ld8f(p.k + o), v = ld8f(p.v + o), g = ld8f(p.g + o);
         const V8 d = ld8f(p.dout + o);
@@ -354,7 +355,7 @@ __global__ void post_bwd_kernel(PostBwd p) {
         }
         st8f(p.dy + o, dy); st8f(p.dr + o, dr); st8f(p.dk + o, dk); st8f(p.dv + o, dv); st8f(p.dg + o, dg);
     }
-    atomic8(p.dln_w + c0, g_w); atomic8(p.dln_b + c0, g_b); atomic8(p.dr_k + c0, g_rk);
+    put_partial(p.part, 3, 0, C, c0, g_w); put_partial(p.part, 3, 1, C, c0, g_b); put_partial(p.part, 3, 2, C, c0, g_rk);
 }
 
 // ---------------------------------------------------------------------------------------------- F6: relu^2
@@ -379,6 +380,11 @@ __global__ __launch_bounds__(256) void relusq_bwd_kernel(long n8, const uint16_t
 
 inline int ok_c(int C) { return C > 0 && C % 64 == 0 && C / 8 <= 1024; }
 inline dim3 tok_grid(long ntok) { return dim3((unsigned)((ntok + TPB - 1) / TPB)); }
+constexpr int BWD_GRID = 1024;         // workgroups (= partial rows) of the backward kernels: 4 per CU
+inline int bwd_grid(long ntok) { long g = (ntok + TPB - 1) / TPB; return (int)(g < BWD_GRID ? g : BWD_GRID); }
+inline void colsum(int G, long width, const float* part, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((width + 255) / 256)), dim3(256), 0, st, G, width, part, out);
+}
 inline int done() { hipError_t e = hipGetLastError(); return e == hipSuccess ? VRWKV_OK : (int)e; }
 
 }  // namespace
@@ -396,15 +402,19 @@ int vrwkv_mix_fwd_bf16(long ntok, int T, int C, int M, const void* x, const void
     return done();
 }
 
+long vrwkv_param_grad_ws_floats(long ntok, int C, int nvec) { return (long)bwd_grid(ntok) * nvec * C; }
+
 int vrwkv_mix_bwd_bf16(long ntok, int T, int C, int M, const void* x, const void* const* mu, const void* const* dout,
-                       void* dx, float* dmu, void* stream) {
-    if (ntok <= 0 || T <= 0 || !x || !mu || !dout || !dx || !dmu || (M != 1 && M != 6)) return VRWKV_EINVAL;
+                       void* dx, float* dmu, float* ws, void* stream) {
+    if (ntok <= 0 || T <= 0 || !x || !mu || !dout || !dx || !dmu || !ws || (M != 1 && M != 6)) return VRWKV_EINVAL;
     if (!ok_c(C) || ntok % T != 0) return VRWKV_ESHAPE;
     Ptrs6 m{}, d{};
     for (int i = 0; i < M; ++i) { m.p[i] = (const uint16_t*)mu[i]; d.p[i] = (const uint16_t*)dout[i]; if (!m.p[i] || !d.p[i]) return VRWKV_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
-    if (M == 6) hipLaunchKernelGGL(mix_bwd_kernel<6>, tok_grid(ntok), dim3(C / 8), 0, st, ntok, T, C, (const uint16_t*)x, m, d, (uint16_t*)dx, dmu);
-    else hipLaunchKernelGGL(mix_bwd_kernel<1>, tok_grid(ntok), dim3(C / 8), 0, st, ntok, T, C, (const uint16_t*)x, m, d, (uint16_t*)dx, dmu);
+    const int G = bwd_grid(ntok);
+    if (M == 6) hipLaunchKernelGGL(mix_bwd_kernel<6>, dim3(G), dim3(C / 8), 0, st, ntok, T, C, (const uint16_t*)x, m, d, (uint16_t*)dx, ws);
+    else hipLaunchKernelGGL(mix_bwd_kernel<1>, dim3(G), dim3(C / 8), 0, st, ntok, T, C, (const uint16_t*)x, m, d, (uint16_t*)dx, ws);
+    colsum(G, (long)M * C, ws, dmu, st);
     return done();
 }
 
@@ -414,11 +424,13 @@ int vrwkv_decay_fwd_bf16(long ntok, int C, const void* h, const void* w0, void* 
     hipLaunchKernelGGL(decay_fwd_kernel, tok_grid(ntok), dim3(C / 8), 0, (hipStream_t)stream, ntok, C, (const uint16_t*)h, (const uint16_t*)w0, (uint16_t*)w);
     return done();
 }
-int vrwkv_decay_bwd_bf16(long ntok, int C, const void* h, const void* w0, const void* dw, void* dh, float* dw0, void* stream) {
-    if (ntok <= 0 || !h || !w0 || !dw || !dh || !dw0) return VRWKV_EINVAL;
+int vrwkv_decay_bwd_bf16(long ntok, int C, const void* h, const void* w0, const void* dw, void* dh, float* dw0, float* ws, void* stream) {
+    if (ntok <= 0 || !h || !w0 || !dw || !dh || !dw0 || !ws) return VRWKV_EINVAL;
     if (!ok_c(C)) return VRWKV_ESHAPE;
-    hipLaunchKernelGGL(decay_bwd_kernel, tok_grid(ntok), dim3(C / 8), 0, (hipStream_t)stream, ntok, C, (const uint16_t*)h, (const uint16_t*)w0,
-                       (const uint16_t*)dw, (uint16_t*)dh, dw0);
+    const int G = bwd_grid(ntok);
+    hipLaunchKernelGGL(decay_bwd_kernel, dim3(G), dim3(C / 8), 0, (hipStream_t)stream, ntok, C, (const uint16_t*)h, (const uint16_t*)w0,
+                       (const uint16_t*)dw, (uint16_t*)dh, ws);
+    colsum(G, C, ws, dw0, (hipStream_t)stream);
     return done();
 }
 
@@ -438,15 +450,17 @@ int vrwkv_kva_bwd_bf16(long ntok, int C, int has_vres, const void* k, const void
                        const void* k_k, const void* k_a, const void* a0, const void* v0,
                        const void* dk2, const void* dv2, const void* dz, const void* db,
                        void* dk, void* dv, void* dvfirst, void* dvl, void* dal,
-                       float* dk_k, float* dk_a, float* da0, float* dv0, void* stream) {
-    if (ntok <= 0 || !k || !al || !k_k || !k_a || !a0 || !dk2 || !dz || !db || !dk || !dal || !dk_k || !dk_a || !da0) return VRWKV_EINVAL;
-    if (has_vres && (!v || !vfirst || !vl || !v0 || !dv2 || !dv || !dvfirst || !dvl || !dv0)) return VRWKV_EINVAL;
+                       float* dparams, float* ws, void* stream) {
+    if (ntok <= 0 || !k || !al || !k_k || !k_a || !a0 || !dk2 || !dz || !db || !dk || !dal || !dparams || !ws) return VRWKV_EINVAL;
+    if (has_vres && (!v || !vfirst || !vl || !v0 || !dv2 || !dv || !dvfirst || !dvl)) return VRWKV_EINVAL;
     if (!ok_c(C)) return VRWKV_ESHAPE;
     KvaBwd p{ntok, C, has_vres, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)vfirst, (const uint16_t*)vl, (const uint16_t*)al,
              (const uint16_t*)k_k, (const uint16_t*)k_a, (const uint16_t*)a0, (const uint16_t*)v0,
              (const uint16_t*)dk2, (const uint16_t*)dv2, (const uint16_t*)dz, (const uint16_t*)db,
-             (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dvfirst, (uint16_t*)dvl, (uint16_t*)dal, dk_k, dk_a, da0, dv0};
-    hipLaunchKernelGGL(kva_bwd_kernel, tok_grid(ntok), dim3(C / 8), 0, (hipStream_t)stream, p);
+             (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dvfirst, (uint16_t*)dvl, (uint16_t*)dal, ws};
+    const int G = bwd_grid(ntok);
+    hipLaunchKernelGGL(kva_bwd_kernel, dim3(G), dim3(C / 8), 0, (hipStream_t)stream, p);
+    colsum(G, 4L * C, ws, dparams, (hipStream_t)stream);       // dparams = [dk_k | dk_a | da0 | dv0], C floats each
     return done();
 }
 
@@ -461,14 +475,16 @@ int vrwkv_post_fwd_bf16(long ntok, int C, float eps, const void* y, const void* 
 }
 int vrwkv_post_bwd_bf16(long ntok, int C, float eps, const void* y, const void* r, const void* k, const void* v, const void* g,
                         const void* ln_w, const void* ln_b, const void* r_k, const void* dout,
-                        void* dy, void* dr, void* dk, void* dv, void* dg, float* dln_w, float* dln_b, float* dr_k, void* stream) {
-    if (ntok <= 0 || !y || !r || !k || !v || !g || !ln_w || !ln_b || !r_k || !dout || !dy || !dr || !dk || !dv || !dg || !dln_w || !dln_b || !dr_k)
+                        void* dy, void* dr, void* dk, void* dv, void* dg, float* dparams, float* ws, void* stream) {
+    if (ntok <= 0 || !y || !r || !k || !v || !g || !ln_w || !ln_b || !r_k || !dout || !dy || !dr || !dk || !dv || !dg || !dparams || !ws)
         return VRWKV_EINVAL;
     if (!ok_c(C)) return VRWKV_ESHAPE;
     PostBwd p{ntok, C, eps, (const uint16_t*)y, (const uint16_t*)r, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)g,
               (const uint16_t*)ln_w, (const uint16_t*)ln_b, (const uint16_t*)r_k, (const uint16_t*)dout,
-              (uint16_t*)dy, (uint16_t*)dr, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dg, dln_w, dln_b, dr_k};
-    hipLaunchKernelGGL(post_bwd_kernel, tok_grid(ntok), dim3(C / 8), 0, (hipStream_t)stream, p);
+              (uint16_t*)dy, (uint16_t*)dr, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dg, ws};
+    const int G = bwd_grid(ntok);
+    hipLaunchKernelGGL(post_bwd_kernel, dim3(G), dim3(C / 8), 0, (hipStream_t)stream, p);
+    colsum(G, 3L * C, ws, dparams, (hipStream_t)stream);       // dparams = [dln_w | dln_b | dr_k]
     return done();
 }
 

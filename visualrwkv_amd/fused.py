@@ -37,6 +37,11 @@ def _p(t):
     return t.data_ptr() if t is not None else 0
 
 
+def _ws(ntok, C, nvec, device):
+    n = hip_lib.load().vrwkv_param_grad_ws_floats(ntok, C, nvec)
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
 class _Mix(torch.autograd.Function):
     """token-shift + M lerps:  out_m = x + (shift(x) - x) * mu_m."""
 
@@ -60,9 +65,10 @@ class _Mix(torch.autograd.Function):
         douts = [d.contiguous() for d in douts]
         _chk(*douts)
         dx = torch.empty_like(x)
-        dmu = torch.zeros(len(mus_c), C, dtype=torch.float32, device=x.device)
+        dmu = torch.empty(len(mus_c), C, dtype=torch.float32, device=x.device)
+        ws = _ws(B * T, C, len(mus_c), x.device)
         rc = hip_lib.load().vrwkv_mix_bwd_bf16(B * T, T, C, len(mus_c), x.data_ptr(), _ptr_array(mus_c), _ptr_array(douts),
-                                               dx.data_ptr(), dmu.data_ptr(), _stream(x))
+                                               dx.data_ptr(), dmu.data_ptr(), ws.data_ptr(), _stream(x))
         hip_lib.check(rc, "vrwkv_mix_bwd_bf16")
         dmu = dmu.to(x.dtype)
         return (dx, *[dmu[i].view(s) for i, s in enumerate(ctx.mu_shapes)])
@@ -91,9 +97,10 @@ class _Decay(torch.autograd.Function):
         dw = dw.contiguous()
         _chk(dw)
         dh = torch.empty_like(h)
-        dw0 = torch.zeros(C, dtype=torch.float32, device=h.device)
+        dw0 = torch.empty(C, dtype=torch.float32, device=h.device)
+        ws = _ws(h.numel() // C, C, 1, h.device)
         rc = hip_lib.load().vrwkv_decay_bwd_bf16(h.numel() // C, C, h.data_ptr(), w0c.data_ptr(), dw.data_ptr(), dh.data_ptr(),
-                                                 dw0.data_ptr(), _stream(h))
+                                                 dw0.data_ptr(), ws.data_ptr(), _stream(h))
         hip_lib.check(rc, "vrwkv_decay_bwd_bf16")
         return dh, dw0.to(h.dtype).view(ctx.w0_shape)
 
@@ -141,12 +148,13 @@ class _Kva(torch.autograd.Function):
         dv = torch.empty_like(k) if has else None
         dvf = torch.empty_like(k) if has else None
         dvl = torch.empty_like(k) if has else None
-        pg = torch.zeros(4, C, dtype=torch.float32, device=k.device)
+        pg = torch.empty(4, C, dtype=torch.float32, device=k.device)
+        ws = _ws(ntok, C, 4, k.device)
         rc = hip_lib.load().vrwkv_kva_bwd_bf16(ntok, C, int(has), k.data_ptr(), _p(v), _p(v_first), _p(vl), al.data_ptr(),
                                                pk.data_ptr(), pa.data_ptr(), p0.data_ptr(), _p(pv),
                                                dk2.data_ptr(), _p(dv2), dz.data_ptr(), db.data_ptr(),
                                                dk.data_ptr(), _p(dv), _p(dvf), _p(dvl), dal.data_ptr(),
-                                               pg[0].data_ptr(), pg[1].data_ptr(), pg[2].data_ptr(), pg[3].data_ptr() if has else 0, _stream(k))
+                                               pg.data_ptr(), ws.data_ptr(), _stream(k))
         hip_lib.check(rc, "vrwkv_kva_bwd_bf16")
         pgb = pg.to(k.dtype)
         s = ctx.shapes
@@ -178,11 +186,12 @@ class _Post(torch.autograd.Function):
         _chk(dout)
         C = y.shape[-1]
         dy, dr, dk, dv, dg = [torch.empty_like(y) for _ in range(5)]
-        pg = torch.zeros(3, C, dtype=torch.float32, device=y.device)
+        pg = torch.empty(3, C, dtype=torch.float32, device=y.device)
+        ws = _ws(y.numel() // C, C, 3, y.device)
         rc = hip_lib.load().vrwkv_post_bwd_bf16(y.numel() // C, C, ctx.eps, y.data_ptr(), r.data_ptr(), k.data_ptr(), v.data_ptr(),
                                                 g.data_ptr(), lw.data_ptr(), lb.data_ptr(), rk.data_ptr(), dout.data_ptr(),
                                                 dy.data_ptr(), dr.data_ptr(), dk.data_ptr(), dv.data_ptr(), dg.data_ptr(),
-                                                pg[0].data_ptr(), pg[1].data_ptr(), pg[2].data_ptr(), _stream(y))
+                                                pg.data_ptr(), ws.data_ptr(), _stream(y))
         hip_lib.check(rc, "vrwkv_post_bwd_bf16")
         pgb = pg.to(y.dtype)
         return dy, dr, dk, dv, dg, pgb[0], pgb[1], pgb[2].view(ctx.rk_shape), None

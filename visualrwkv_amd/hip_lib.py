@@ -21,13 +21,14 @@ PROTOTYPES = {
     "vrwkv_wkv7_set_forward_variant": (_c_int, [_c_int]),
     "vrwkv_wkv7_set_backward_variant": (_c_int, [_c_int]),
     "vrwkv_mix_fwd_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int, _c_int] + [_c_void_p] * 4),
-    "vrwkv_mix_bwd_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int, _c_int] + [_c_void_p] * 6),
+    "vrwkv_param_grad_ws_floats": (ctypes.c_long, [ctypes.c_long, _c_int, _c_int]),
+    "vrwkv_mix_bwd_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int, _c_int] + [_c_void_p] * 7),
     "vrwkv_decay_fwd_bf16": (_c_int, [ctypes.c_long, _c_int] + [_c_void_p] * 4),
-    "vrwkv_decay_bwd_bf16": (_c_int, [ctypes.c_long, _c_int] + [_c_void_p] * 6),
+    "vrwkv_decay_bwd_bf16": (_c_int, [ctypes.c_long, _c_int] + [_c_void_p] * 7),
     "vrwkv_kva_fwd_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int] + [_c_void_p] * 14),
-    "vrwkv_kva_bwd_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int] + [_c_void_p] * 23),
+    "vrwkv_kva_bwd_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int] + [_c_void_p] * 21),
     "vrwkv_post_fwd_bf16": (_c_int, [ctypes.c_long, _c_int, ctypes.c_float] + [_c_void_p] * 10),
-    "vrwkv_post_bwd_bf16": (_c_int, [ctypes.c_long, _c_int, ctypes.c_float] + [_c_void_p] * 18),
+    "vrwkv_post_bwd_bf16": (_c_int, [ctypes.c_long, _c_int, ctypes.c_float] + [_c_void_p] * 17),
     "vrwkv_relusq_fwd_bf16": (_c_int, [ctypes.c_long] + [_c_void_p] * 3),
     "vrwkv_relusq_bwd_bf16": (_c_int, [ctypes.c_long] + [_c_void_p] * 4),
     "vrwkv_adamw_step_bf16": (_c_int, [ctypes.c_long] + [_c_void_p] * 5 + [ctypes.c_float] * 5 + [_c_int, ctypes.c_float, ctypes.c_long, ctypes.c_long, _c_void_p]),
