@@ -51,8 +51,9 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H,
                              void* stream);
 
 /* Launch-shape override for benchmarking/tests: variant < 0 restores the automatic choice.
- * forward variants: 0/1/2 = sequential VALU kernel with 1/2/4 waves per head, 3 = chunked bf16x3
- * MFMA kernel (the default). */
+ * forward variants: 0/1/2 = sequential VALU kernel with 1/2/4 waves per head, 3 = chunked bf16x3 MFMA kernel
+ * (4 waves, phases back to back), 4..7 = chunked MFMA kernel with producer/consumer wave specialisation
+ * (4: 16-byte stores + producer priority, 5: scalar stores + priority [default], 6/7: same without priority). */
 int vrwkv_wkv7_set_forward_variant(int variant);
 /* backward variants: 0 = sequential VALU kernel, 1 = chunked bf16x3 MFMA kernel (the default). */
 int vrwkv_wkv7_set_backward_variant(int variant);
@@ -106,6 +107,13 @@ int vrwkv_adamw_step_bf16(long n, float* master, float* m, float* v, const void*
 
 /* out[0] += sum of squares of a bf16 buffer (n % 8 == 0); used for gradient_clip_val=1.0 (train.py:92). */
 int vrwkv_sqnorm_bf16(long n, const void* x, float* out, void* stream);
+
+/* Profiling build of the chunked WKV7 kernels: same computation, plus dbg[0..15] (device memory, zero it first)
+ * += shader-clock cycles that workgroup 0 spent in each phase.  backward = 0: uses w..a, y, s, sa; 1: all. */
+int vrwkv_wkv7_profile_bf16(int backward, int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
+                            const void* z, const void* a, const void* dy, void* y, float* s, float* sa,
+                            void* dw, void* dq, void* dk, void* dv, void* dz, void* da,
+                            unsigned long long* dbg, void* stream);
 
 /* Hardware probe for the GPU tests (MFMA lane maps, cross-lane primitives); one wave.
  * which: 0 = 16x16x4 f32, 1 = 32x32x2 f32, 2 = 16x16x32 bf16, 3 = 32x32x16 bf16 (d = a*b, row-major

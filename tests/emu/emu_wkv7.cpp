@@ -4,6 +4,7 @@
 #include <wkv7_kernels.h>
 #include <wkv7_chunked.h>
 #include <wkv7_chunked_bwd.h>
+#include <wkv7_fwd_v3.h>
 
 extern "C" {
 
@@ -15,7 +16,8 @@ int emu_wkv7_forward(int B, int T, int H, const void* w, const void* q, const vo
     if (variant == 0) emu::launch(grid, dim3(64), [&] { wkv7::fwd_kernel<16, 8>(p); });
     else if (variant == 1) emu::launch(grid, dim3(128), [&] { wkv7::fwd_kernel<8, 16>(p); });
     else if (variant == 2) emu::launch(grid, dim3(256), [&] { wkv7::fwd_kernel<4, 16>(p); });
-    else emu::launch(grid, dim3(256), [&] { wkv7c::fwd_kernel(p); });
+    else if (variant == 3) emu::launch(grid, dim3(256), [&] { wkv7c::fwd_kernel_t<false>(p); });
+    else emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false>(p); });
     return 0;
 }
 
@@ -36,7 +38,7 @@ int emu_wkv7_backward_chunked(int B, int T, int H, const void* w, const void* q,
                     (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
                     (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
     static_assert(sizeof(wkv7c::LdsB) <= 160 * 1024, "LDS budget");
-    emu::launch(dim3((unsigned)(B * H)), dim3(256), [&] { wkv7c::bwd_kernel(p); });
+    emu::launch(dim3((unsigned)(B * H)), dim3(256), [&] { wkv7c::bwd_kernel_t<false>(p); });
     return (int)sizeof(wkv7c::LdsB);
 }
 

@@ -36,6 +36,7 @@ DEVFN float fast_tanh(float x) { return tanhf(x); }
 DEVFN float fast_rsqrt(float x) { return 1.0f / sqrtf(x); }
 
 DEVFN int lane_id() { return emu::flat_tid() & 63; }
+DEVFN int uniform_i32(int x) { return x; }
 
 // value of `x` held by lane `src` of the calling lane's wave (all lanes must call)
 DEVFN uint32_t emu_wave_read(uint32_t x, int src) {
@@ -61,6 +62,26 @@ DEVFN float lane_xor1(float x) { return lane_xor(x, 1); }
 DEVFN float lane_xor2(float x) { return lane_xor(x, 2); }
 DEVFN float lane_half_mirror(float x) { int l = lane_id(); return __uint_as_float(emu_wave_read(__float_as_uint(x), (l & ~7) | (7 - (l & 7)))); }
 DEVFN float lane_mirror(float x) { int l = lane_id(); return __uint_as_float(emu_wave_read(__float_as_uint(x), (l & ~15) | (15 - (l & 15)))); }
+
+DEVFN f32x4 quad_transpose(f32x4 x) {
+    const int m = lane_id();
+    const bool o1 = m & 1, o2 = m & 2;
+    float a0 = x[0], a1 = x[1], a2 = x[2], a3 = x[3];
+    {
+        const float s01 = o1 ? a0 : a1, s23 = o1 ? a2 : a3;
+        const float r01 = lane_xor1(s01), r23 = lane_xor1(s23);
+        a0 = o1 ? r01 : a0; a1 = o1 ? a1 : r01;
+        a2 = o1 ? r23 : a2; a3 = o1 ? a3 : r23;
+    }
+    {
+        const float s02 = o2 ? a0 : a2, s13 = o2 ? a1 : a3;
+        const float r02 = lane_xor2(s02), r13 = lane_xor2(s13);
+        a0 = o2 ? r02 : a0; a2 = o2 ? a2 : r02;
+        a1 = o2 ? r13 : a1; a3 = o2 ? a3 : r13;
+    }
+    f32x4 y = {a0, a1, a2, a3};
+    return y;
+}
 
 template <int LOG2> DEVFN float group_sum(float x) {
     if (LOG2 >= 1) x += lane_xor1(x);
@@ -150,5 +171,8 @@ DEVFN f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 
 DEVFN char* dyn_lds() { static __attribute__((aligned(16))) char buf[160 * 1024]; return buf; }
 
+template <int P> DEVFN void wave_priority() {}
+DEVFN unsigned long long clock64_() { return 0; }
 DEVFN void block_sync() { emu::block_barrier(); }
+DEVFN void block_sync_lds() { emu::block_barrier(); }
 DEVFN void wave_lds_fence() { emu::wave_barrier(); }

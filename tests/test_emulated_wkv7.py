@@ -14,7 +14,7 @@ def P(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_forward_variants(emu_lib, variant):
     B, T, H, N = 2, 32, 2, 64
     w, q, k, v, z, a, _ = make_inputs(B, T, H, seed=variant)
@@ -23,7 +23,7 @@ def test_forward_variants(emu_lib, variant):
     emu_lib.emu_wkv7_forward(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(y), P(s), P(sa), variant)
     assert rel_rms(y.float(), yr.float()) < 1e-3
     assert (y != yr).float().mean() < 0.01
-    assert rel_rms(s, sr) < 1e-5 and rel_rms(sa, sar) < 1e-5
+    assert rel_rms(s, sr) < 2e-5 and rel_rms(sa, sar) < 2e-5
 
 
 def test_backward(emu_lib):

@@ -45,7 +45,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-I", CSRC, "-I", os.path.join(REPO_DIR, "include"),
-           "-Wno-unused-result", *_sources(), "-o", LIB_PATH]
+           "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form", *_sources(), "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

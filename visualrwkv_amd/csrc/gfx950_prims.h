@@ -71,6 +71,31 @@ DEVFN float lane_mirror(float x) { return dpp_mov<0x140>(x); }       // i <-> 15
 DEVFN float lane_xor(float x, int mask) { return __shfl_xor(x, mask, 64); }
 DEVFN float lane_bcast(float x, int src_lane) { return __shfl(x, src_lane, 64); }
 DEVFN int lane_id() { return (int)(threadIdx.x & 63); }
+// value is wave-uniform by construction (e.g. threadIdx.x >> 6): make that provable -> scalar branches
+DEVFN int uniform_i32(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// 4x4 transpose inside every quad of lanes: in: lane m (= lane&3) holds x[r], out: lane m holds x_r[m] of lane r
+// (two butterfly stages of quad_perm DPP + selects).  Turns "4 consecutive rows, one column per lane" MFMA
+// fragments into "one row, 4 consecutive columns per lane", i.e. 16-byte stores.
+DEVFN f32x4 quad_transpose(f32x4 x) {
+    const int m = lane_id();
+    const bool o1 = m & 1, o2 = m & 2;
+    float a0 = x[0], a1 = x[1], a2 = x[2], a3 = x[3];
+    {   // stage 1: partner lane^1, element index bit 0
+        const float s01 = o1 ? a0 : a1, s23 = o1 ? a2 : a3;
+        const float r01 = lane_xor1(s01), r23 = lane_xor1(s23);
+        a0 = o1 ? r01 : a0; a1 = o1 ? a1 : r01;
+        a2 = o1 ? r23 : a2; a3 = o1 ? a3 : r23;
+    }
+    {   // stage 2: partner lane^2, element index bit 1
+        const float s02 = o2 ? a0 : a2, s13 = o2 ? a1 : a3;
+        const float r02 = lane_xor2(s02), r13 = lane_xor2(s13);
+        a0 = o2 ? r02 : a0; a2 = o2 ? a2 : r02;
+        a1 = o2 ? r13 : a1; a3 = o2 ? a3 : r13;
+    }
+    f32x4 y = {a0, a1, a2, a3};
+    return y;
+}
 
 // Sum over the 2^LOG2 lanes that share the high lane bits (all-reduce: every lane gets the sum).
 template <int LOG2> DEVFN float group_sum(float x) {
@@ -99,8 +124,19 @@ DEVFN f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin
 extern __shared__ __attribute__((aligned(16))) char vrwkv_dyn_lds[];
 DEVFN char* dyn_lds() { return vrwkv_dyn_lds; }
 
+// static wave priority (0..3); scalar, ignores EXEC: call only under wave-uniform control flow
+template <int P> DEVFN void wave_priority() { __builtin_amdgcn_s_setprio(P); }
+
+// shader clock (s_memtime), for in-kernel phase timing
+DEVFN unsigned long long clock64_() { return __builtin_readcyclecounter(); }
+
 // ---------------------------------------------------------------- sync
 DEVFN void block_sync() { __syncthreads(); }
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for
+// global prefetch loads issued for a later chunk (measured: ~2.9k cycles per barrier in the WKV7 forward).
+// Global loads stay tracked by the compiler (it waits before their first use); global stores need no ordering
+// against other waves of the workgroup here.
+DEVFN void block_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // LDS ops of one wave execute in order; this only stops the compiler from moving LDS accesses
 // across the point where lanes exchange data through LDS.
 DEVFN void wave_lds_fence() {

@@ -6,6 +6,7 @@
 #include <wkv7_kernels.h>
 #include <wkv7_chunked.h>
 #include <wkv7_chunked_bwd.h>
+#include <wkv7_fwd_v3.h>
 
 namespace {
 
@@ -42,7 +43,7 @@ const char* vrwkv_strerror(int code) {
 }
 
 int vrwkv_wkv7_set_forward_variant(int variant) {
-    if (variant > 3) return VRWKV_EINVAL;
+    if (variant > 7) return VRWKV_EINVAL;
     g_fwd_variant = variant;
     return VRWKV_OK;
 }
@@ -66,12 +67,28 @@ int vrwkv_wkv7_forward_bf16(int B, int T, int H, const void* w, const void* q, c
     hipStream_t st = (hipStream_t)stream;
     const long heads = (long)B * H;
     int variant = g_fwd_variant;
-    if (variant < 0) variant = 3;                                           // chunked MFMA kernel
+    if (variant < 0) variant = 5;                                           // chunked MFMA, producer/consumer waves
     const dim3 grid((unsigned)heads);
     if (variant == 0) hipLaunchKernelGGL((wkv7::fwd_kernel<16, 8>), grid, dim3(64), 0, st, p);
     else if (variant == 1) hipLaunchKernelGGL((wkv7::fwd_kernel<8, 16>), grid, dim3(128), 0, st, p);
     else if (variant == 2) hipLaunchKernelGGL((wkv7::fwd_kernel<4, 16>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(wkv7c::fwd_kernel, grid, dim3(256), 0, st, p);
+    else if (variant == 3) hipLaunchKernelGGL(wkv7c::fwd_kernel_t<false>, grid, dim3(256), 0, st, p);
+    else {
+        // variants 4..7: producer/consumer kernel; bit 0 of (variant-4): narrow stores, bit 1: no producer priority
+        auto launch = [&](auto kern) -> int {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsF));
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(kern, grid, dim3(512), sizeof(wkv7c::LdsF), st, p);
+            return 0;
+        };
+        int e = 0;
+        if (variant == 4) e = launch(&wkv7c::fwd_kernel_v3<false, true, 1>);
+        else if (variant == 5) e = launch(&wkv7c::fwd_kernel_v3<false, false, 1>);
+        else if (variant == 6) e = launch(&wkv7c::fwd_kernel_v3<false, true, 0>);
+        else e = launch(&wkv7c::fwd_kernel_v3<false, false, 0>);
+        if (e) return e;
+    }
     return finish_launch();
 }
 
@@ -95,12 +112,46 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H, const void* w, const void* q, 
     } else {
         static bool attr_set = false;     // > 64 KB of LDS needs the opt-in once per process
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::bwd_kernel),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::bwd_kernel_t<false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsB));
             if (e != hipSuccess) return (int)e;
             attr_set = true;
         }
-        hipLaunchKernelGGL(wkv7c::bwd_kernel, grid, dim3(256), sizeof(wkv7c::LdsB), st, p);
+        hipLaunchKernelGGL(wkv7c::bwd_kernel_t<false>, grid, dim3(256), sizeof(wkv7c::LdsB), st, p);
+    }
+    return finish_launch();
+}
+
+// Profiling builds of the chunked kernels: dbg[0..15] (device, zeroed by the caller) receives the shader-clock
+// cycles workgroup 0 spent in each phase (see WKV_STAMP in wkv7_chunked*.h).
+int vrwkv_wkv7_profile_bf16(int backward, int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
+                            const void* z, const void* a, const void* dy, void* y, float* s, float* sa,
+                            void* dw, void* dq, void* dk, void* dv, void* dz, void* da,
+                            unsigned long long* dbg, void* stream) {
+    int rc = check_common(B, T, H);
+    if (rc) return rc;
+    if (!dbg) return VRWKV_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((long)B * H));
+    if (!backward) {
+        wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
+                        (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, s, sa, dbg};
+        if (backward == 0 && g_fwd_variant == 3) {
+            hipLaunchKernelGGL(wkv7c::fwd_kernel_t<true>, grid, dim3(256), 0, st, p);
+        } else {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::fwd_kernel_v3<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsF));
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(wkv7c::fwd_kernel_v3<true>, grid, dim3(512), sizeof(wkv7c::LdsF), st, p);
+        }
+    } else {
+        wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
+                        (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
+                        (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da, dbg};
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::bwd_kernel_t<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsB));
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(wkv7c::bwd_kernel_t<true>, grid, dim3(256), sizeof(wkv7c::LdsB), st, p);
     }
     return finish_launch();
 }

@@ -192,8 +192,25 @@ DEVFN bf16x8 ld_perm(const uint16_t (*M)[TJ], int row, int kb, int g) {
     return mk8(ld8(p), ld8(p + 16));
 }
 
-__global__ __launch_bounds__(256) void fwd_kernel(FwdArgs p) {
+// PROF: per-phase shader-clock deltas are accumulated in registers (s_memtime is scalar) and written to
+// p.dbg once at kernel end by WKV_STAMP_FLUSH -- a stamp that touched memory would bill its own latency to the
+// next phase.
+#define WKV_STAMP_DECL unsigned long long tprev_ = PROF ? clock64_() : 0ull, tacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define WKV_STAMP(slot)                                                        \
+    if (PROF) {                                                                \
+        const unsigned long long now_ = clock64_();                            \
+        tacc_[slot] += now_ - tprev_;                                          \
+        tprev_ = now_;                                                         \
+    }
+#define WKV_STAMP_FLUSH(who, base, n)                                          \
+    if (PROF && blockIdx.x == 0 && tid == (who)) {                             \
+        for (int i_ = 0; i_ < (n); ++i_) p.dbg[(base) + i_] = tacc_[i_];       \
+    }
+
+template <bool PROF>
+__global__ __launch_bounds__(256) void fwd_kernel_t(FwdArgs p) {
     __shared__ __attribute__((aligned(16))) Lds lds;
+    WKV_STAMP_DECL
     const int T = p.T, H = p.H;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -213,9 +230,13 @@ __global__ __launch_bounds__(256) void fwd_kernel(FwdArgs p) {
     for (int c = 0; c < nchunk; ++c) {
         prep(lds, rc, wave, lane);
         if (c + 1 < nchunk) load_chunk(rc, p, prep_off + (size_t)(c + 1) * L * tstride);
-        block_sync();
+        WKV_STAMP(0)
+        block_sync_lds();
+        WKV_STAMP(1)
         scores(lds, wave, lane);
-        block_sync();
+        WKV_STAMP(2)
+        block_sync_lds();
+        WKV_STAMP(3)
 
         // ---------------- phase 3
         uint2 sh[4], sl[4];
@@ -285,8 +306,12 @@ __global__ __launch_bounds__(256) void fwd_kernel(FwdArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) sdst[(size_t)(16 * jb + 4 * g + r) * N] = acc[r];
         }
-        block_sync();
+        WKV_STAMP(4)
+        block_sync_lds();
+        WKV_STAMP(5)
     }
+    WKV_STAMP_FLUSH(0, 0, 6)
 }
+
 
 }  // namespace wkv7c

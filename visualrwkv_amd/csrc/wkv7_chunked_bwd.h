@@ -118,8 +118,10 @@ DEVFN void store_dscore(LdsB& lds, int slot, f32x4 d, int c16, int g, int mode) 
     st8(&lds.dsc[slot][1][c16][4 * g], l);
 }
 
-__global__ __launch_bounds__(256) void bwd_kernel(BwdArgs p) {
+template <bool PROF>
+__global__ __launch_bounds__(256) void bwd_kernel_t(BwdArgs p) {
     LdsB& lds = *reinterpret_cast<LdsB*>(dyn_lds());
+    WKV_STAMP_DECL
     const int T = p.T, H = p.H;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -144,20 +146,42 @@ __global__ __launch_bounds__(256) void bwd_kernel(BwdArgs p) {
         }
     }
 
+    // inputs of the chunk being processed are fetched one chunk ahead (registers)
+    struct Raw { uint2 w, q, k, z, a, v, dy; float4 sa; } raw;
+    f32x4 S0n[4];
+    auto fetch = [&](int c) {
+        const size_t off = prep_off + (size_t)c * L * tstride;
+        raw.w = *reinterpret_cast<const uint2*>(p.w + off); raw.q = *reinterpret_cast<const uint2*>(p.q + off);
+        raw.k = *reinterpret_cast<const uint2*>(p.k + off); raw.z = *reinterpret_cast<const uint2*>(p.z + off);
+        raw.a = *reinterpret_cast<const uint2*>(p.a + off); raw.v = *reinterpret_cast<const uint2*>(p.v + off);
+        raw.dy = *reinterpret_cast<const uint2*>(p.dy + off); raw.sa = *reinterpret_cast<const float4*>(p.sa + off);
+        if (c > 0) {          // chunk-start state S0 = s[c-1] as S[i][j] tiles (zero for the first chunk)
+            const float* sp = sbase + (size_t)(c - 1) * N * N + (size_t)(16 * wave + c16) * N + 4 * g;
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) {
+                const float4 x = *reinterpret_cast<const float4*>(sp + 16 * ib);
+                S0n[ib][0] = x.x; S0n[ib][1] = x.y; S0n[ib][2] = x.z; S0n[ib][3] = x.w;
+            }
+        } else {
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) S0n[ib] = zero4();
+        }
+    };
+    fetch(nchunk - 1);
+
     for (int c = nchunk - 1; c >= 0; --c) {
         const size_t coff = prep_off + (size_t)c * L * tstride;
         // ------------------------------------------------------------ phase 1: operands
         float q[4], k[4], z[4], a[4], lw[4], cc[4], cp[4], ic[4];
+        f32x4 S0[4];
         {
             float wr[4];
-            unpack4(*reinterpret_cast<const uint2*>(p.w + coff), wr);
-            unpack4(*reinterpret_cast<const uint2*>(p.q + coff), q);
-            unpack4(*reinterpret_cast<const uint2*>(p.k + coff), k);
-            unpack4(*reinterpret_cast<const uint2*>(p.z + coff), z);
-            unpack4(*reinterpret_cast<const uint2*>(p.a + coff), a);
-            const uint2 rv = *reinterpret_cast<const uint2*>(p.v + coff);
-            const uint2 rdy = *reinterpret_cast<const uint2*>(p.dy + coff);
-            const float4 rsa = *reinterpret_cast<const float4*>(p.sa + coff);
+            unpack4(raw.w, wr); unpack4(raw.q, q); unpack4(raw.k, k); unpack4(raw.z, z); unpack4(raw.a, a);
+            const uint2 rv = raw.v;
+            const uint2 rdy = raw.dy;
+            const float4 rsa = raw.sa;
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) S0[ib] = S0n[ib];
             float zt[4], qt[4], ah[4], kh[4], ab[4], kb[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -188,20 +212,10 @@ __global__ __launch_bounds__(256) void bwd_kernel(BwdArgs p) {
             split4(sav, hh, ll); st8(&lds.ti[2][c16][c0], hh); st8(&lds.ti[3][c16][c0], ll);
             if (c16 == 15) *reinterpret_cast<float4*>(&lds.cl[c0]) = make_float4(cc[0], cc[1], cc[2], cc[3]);
         }
-        // chunk-start state S0 = s[c-1] as S[i][j] tiles (zero for the first chunk)
-        f32x4 S0[4];
-        if (c > 0) {
-            const float* sp = sbase + (size_t)(c - 1) * N * N + (size_t)(16 * wave + c16) * N + 4 * g;
-#pragma unroll
-            for (int ib = 0; ib < 4; ++ib) {
-                const float4 x = *reinterpret_cast<const float4*>(sp + 16 * ib);
-                S0[ib][0] = x.x; S0[ib][1] = x.y; S0[ib][2] = x.z; S0[ib][3] = x.w;
-            }
-        } else {
-#pragma unroll
-            for (int ib = 0; ib < 4; ++ib) S0[ib] = zero4();
-        }
-        block_sync();
+        if (c > 0) fetch(c - 1);            // prefetch: consumed in the next iteration
+        WKV_STAMP(0)
+        block_sync_lds();
+        WKV_STAMP(1)
 
         // ------------------------------------------------------------ phase 2: scores (one matrix per wave)
         if (wave == 1) {          // (Qt Ah^T)[t][s] held as lane c16 = s, r <-> t: A image of M_qa^T
@@ -245,7 +259,9 @@ __global__ __launch_bounds__(256) void bwd_kernel(BwdArgs p) {
             uint2 hh, ll; split4(Tc, hh, ll);                   // Tc[r] = T[4g+r][c16] = T^T[c16][4g+r]
             st8(&lds.sc[3][0][c16][4 * g], hh); st8(&lds.sc[3][1][c16][4 * g], ll);
         }
-        block_sync();
+        WKV_STAMP(2)
+        block_sync_lds();
+        WKV_STAMP(3)
 
         // ------------------------------------------------------------ phase 3: i-split products (i = 16*wave + c16)
         {
@@ -286,7 +302,9 @@ __global__ __launch_bounds__(256) void bwd_kernel(BwdArgs p) {
                 dS1[jb] = acc;
             }
         }
-        block_sync();
+        WKV_STAMP(4)
+        block_sync_lds();
+        WKV_STAMP(5)
 
         // ------------------------------------------------------------ phase 4: score gradients (one matrix per wave)
         if (wave == 0) {          // dM_za = tril_(dR SA^T)
@@ -302,7 +320,9 @@ __global__ __launch_bounds__(256) void bwd_kernel(BwdArgs p) {
             store_dscore(lds, 7, dot64<false, false>(lds.ti[1], lds.ti[1], lds.ti[0], lds.ti[0], c16, g), c16, g, 2);
             store_dscore(lds, 6, dot64<false, false>(lds.ti[0], lds.ti[0], lds.ti[1], lds.ti[1], c16, g), c16, g, 3);
         }
-        block_sync();
+        WKV_STAMP(6)
+        block_sync_lds();
+        WKV_STAMP(7)
 
         // ------------------------------------------------------------ phase 5: j-split products (j = 16*wave + c16)
         {
@@ -363,6 +383,7 @@ __global__ __launch_bounds__(256) void bwd_kernel(BwdArgs p) {
                 lds.res[3][4 * g + r][j] = dKh[r];
             }
         }
+        WKV_STAMP(8)
         wave_lds_fence();
         // ------------------------------------------------------------ element-wise tail (lane: token c16, columns c0..c0+3)
         {
@@ -389,8 +410,11 @@ __global__ __launch_bounds__(256) void bwd_kernel(BwdArgs p) {
             *reinterpret_cast<uint2*>(p.dz + coff) = make_uint2(cvt_pk_bf16(dz[0], dz[1]), cvt_pk_bf16(dz[2], dz[3]));
             *reinterpret_cast<uint2*>(p.da + coff) = make_uint2(cvt_pk_bf16(da[0], da[1]), cvt_pk_bf16(da[2], da[3]));
         }
-        block_sync();
+        WKV_STAMP(9)
+        block_sync_lds();
+        WKV_STAMP(10)
     }
+    WKV_STAMP_FLUSH(0, 0, 11)
 }
 
 }  // namespace wkv7c

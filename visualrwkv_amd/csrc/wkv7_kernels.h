@@ -33,6 +33,7 @@ struct FwdArgs {
     uint16_t* y;                             // bf16 (B,T,H,N)
     float* s;                                // f32 (B,H,T/16,N,N)  holds S^T at chunk ends
     float* sa;                               // f32 (B,T,H,N)
+    unsigned long long* dbg = nullptr;       // optional: per-phase cycle counts of workgroup 0 (profiling builds)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -178,6 +179,7 @@ struct BwdArgs {
     const float* s;                               // f32 (B,H,T/16,N,N)
     const float* sa;                              // f32 (B,T,H,N)
     uint16_t *dw, *dq, *dk, *dv, *dz, *da;        // bf16 (B,T,H,N)
+    unsigned long long* dbg = nullptr;
 };
 
 // One workgroup (4 waves) per head; wave `wv` owns state rows [16 wv, 16 wv + 16).  The backward
