@@ -110,8 +110,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or os.environ.get("VRWKV_FORCE_COLLECTIVES") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
@@ -130,7 +131,8 @@ def main():
                 p.normal_(0, 0.01)
     model = model.to(torch.bfloat16)
     model.freeze_emb()         # fine-tune recipe: ViT and embedding frozen (train.py:196, model.py:349)
-    engine = Zero1Engine(model, lr=2e-5, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0, grad_clip=1.0, bucket_mb=200.0)
+    engine = Zero1Engine(model, lr=2e-5, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0, grad_clip=1.0, bucket_mb=200.0,
+                         force_collectives=os.environ.get("VRWKV_FORCE_COLLECTIVES") == "1")
     batch = synthetic_batch(a.micro_bsz, a.ctx_len, a.img_tokens, towers, dev, seed=1000 + rank)
 
     def step():
@@ -194,7 +196,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.n_embd, a.ctx_len)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

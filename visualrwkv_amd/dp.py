@@ -61,7 +61,7 @@ class _Bucket:
 class Zero1Engine:
     def __init__(self, model: torch.nn.Module, lr: float = 1e-4, betas=(0.9, 0.99), eps: float = 1e-8,
                  weight_decay: float = 0.0, grad_clip: float = 1.0, bucket_mb: float = 200.0,
-                 process_group=None, overlap: bool = True):
+                 process_group=None, overlap: bool = True, force_collectives: bool = False):
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.grad_clip = grad_clip
@@ -69,12 +69,15 @@ class Zero1Engine:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.step_count = 0
+        # force_collectives: run the full hook / side-stream / reduce-scatter / all-gather path even with one
+        # rank (used to exercise the RCCL code path on a single-GPU box)
+        self.collective = self.world > 1 or (force_collectives and dist.is_initialized())
         params = [p for p in model.parameters() if p.requires_grad]
         assert params, "nothing to train"
         self.device = params[0].device
         self.dtype = params[0].dtype
         self.on_gpu = self.device.type == "cuda"
-        self.overlap = overlap and self.on_gpu and self.world > 1
+        self.overlap = overlap and self.on_gpu and self.collective
         wd = [p for p in params if len(p.squeeze().shape) >= 2]
         nowd = [p for p in params if len(p.squeeze().shape) < 2]
         # later layers produce their gradients first: lay the flat buffer out in reverse registration order
@@ -123,7 +126,7 @@ class Zero1Engine:
                 self.buckets[i].n_params += 1
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
         self._hooks = []
-        if self.world > 1:
+        if self.collective:
             for k, p in enumerate(ordered):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(k)))
         self._sq = torch.zeros(1, dtype=torch.float32, device=self.device)
@@ -152,7 +155,7 @@ class Zero1Engine:
         return hook
 
     def _launch_reduce(self, b: _Bucket):
-        if self.world == 1:
+        if not self.collective:
             return
         buf = self.flat_grad[b.start:b.end]
         if self.overlap:
@@ -186,7 +189,7 @@ class Zero1Engine:
         the updated bf16 parameters.  Returns the pre-clip global gradient norm."""
         lr = self.lr if lr is None else lr
         self.step_count += 1
-        if self.world > 1:
+        if self.collective:
             for b in self.buckets:                   # buckets whose hooks never all fired (unused params)
                 if b.pending > 0:
                     self._launch_reduce(b)
@@ -200,7 +203,7 @@ class Zero1Engine:
         for b in self.buckets:
             g = self._piece(self.flat_grad, b)
             self._sqnorm(g, self._sq)
-        if self.world > 1:
+        if self.collective:
             dist.all_reduce(self._sq, group=self.pg)
         gnorm = float(self._sq.sqrt()) * inv_world
         scale = inv_world
@@ -208,7 +211,7 @@ class Zero1Engine:
             scale *= min(1.0, self.grad_clip / (gnorm + 1e-6))
         for b in self.buckets:
             self._adamw(b, lr, scale)
-        if self.world > 1:
+        if self.collective:
             for b in self.buckets:
                 buf = self.flat_param[b.start:b.end]
                 piece = buf[self.rank * b.piece:(self.rank + 1) * b.piece]
