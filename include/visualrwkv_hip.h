@@ -96,6 +96,13 @@ int vrwkv_post_bwd_bf16(long ntok, int C, float eps, const void* y, const void* 
 int vrwkv_relusq_fwd_bf16(long n, const void* h, void* y, void* stream);
 int vrwkv_relusq_bwd_bf16(long n, const void* h, const void* dy, void* dh, void* stream);
 
+/* Softmax attention forward of the frozen ViT towers: o = softmax(q k^T / sqrt(D)) v for D in {64, 72}
+ * (replaces the attention inside the timm VisionTransformer blocks run by SamDinoSigLIPViTBackbone.forward,
+ * VisualRWKV-v7/v7.00/src/vision.py:123-134).  q/k/v element (b,l,h,d) at b*stride_b + l*stride_l + h*stride_h + d
+ * (bf16, strides in elements, multiples of 8); o is (B,L,H,D) contiguous bf16. */
+int vrwkv_attention_fwd_bf16(int B, int L, int H, int D, const void* q, const void* k, const void* v,
+                             long stride_b, long stride_l, long stride_h, void* o, void* stream);
+
 /* Fused AdamW step on a flat ZeRO-1 shard (replaces DeepSpeed's FusedAdam(adam_w_mode=True) that the
  * reference configures in VisualRWKV-v7/v7.00/src/model.py:410): fp32 master/m/v, bf16 gradient in, bf16
  * parameter out, gradient pre-scaled by grad_scale (clip coefficient / world size), bias correction for

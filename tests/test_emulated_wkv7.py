@@ -35,3 +35,18 @@ def test_backward(emu_lib):
     emu_lib.emu_wkv7_backward(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(dy), P(s), P(sa), *[P(o) for o in outs])
     for name, o, r in zip(["dw", "dq", "dk", "dv", "dz", "da"], outs, ref):
         assert rel_rms(o.float(), r.float()) < 1e-3, name
+
+
+@pytest.mark.parametrize("D,L", [(64, 70), (72, 48)])
+def test_attention_forward(emu_lib, D, L):
+    """ViT attention kernel (csrc/attention_kernels.h) vs fp32 softmax attention; q/k/v are strided slices of one
+    fused qkv tensor as in the towers; L is not a multiple of the key tile (tail masking)."""
+    B, H = 1, 2
+    g = torch.Generator().manual_seed(D)
+    qkv = (torch.randn(B, L, 3, H, D, generator=g)).bfloat16()
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    o = torch.zeros(B, L, H, D, dtype=torch.bfloat16)
+    sb, sl, sh, _ = q.stride()
+    emu_lib.emu_attention_fwd(B, L, H, D, P(q), P(k), P(v), ctypes.c_long(sb), ctypes.c_long(sl), ctypes.c_long(sh), P(o))
+    ref = torch.nn.functional.scaled_dot_product_attention(q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2)).transpose(1, 2)
+    assert rel_rms(o.float(), ref) < 1e-2
