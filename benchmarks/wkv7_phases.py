@@ -7,7 +7,7 @@ from benchmarks.wkv7_micro import synth_inputs
 from visualrwkv_amd import hip_lib
 
 FWD = ["c_top", "c_main1", "c_waitA", "c_main2", "c_waitB", "-", "-", "-", "p_prep", "p_waitA", "p_scores", "p_waitB"]
-BWD = ["prep", "wait1", "scores", "wait2", "isplit", "wait3", "dscores", "wait4", "jsplit", "tail", "wait5"]
+BWD = ["c_isplit", "c_waitX", "c_jsplit1", "c_waitY", "c_jsplit2_tail", "c_waitZ", "-", "-", "p_prepA", "p_waitX", "p_prepB_dM", "p_waitY", "p_scores", "p_waitZ"]
 
 def run(B=8, T=2624, H=32):
     lib = hip_lib.load()

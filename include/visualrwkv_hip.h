@@ -55,7 +55,8 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H,
  * (4 waves, phases back to back), 4..7 = chunked MFMA kernel with producer/consumer wave specialisation
  * (4: 16-byte stores + producer priority, 5: scalar stores + priority [default], 6/7: same without priority). */
 int vrwkv_wkv7_set_forward_variant(int variant);
-/* backward variants: 0 = sequential VALU kernel, 1 = chunked bf16x3 MFMA kernel (the default). */
+/* backward variants: 0 = sequential VALU kernel, 1 = chunked bf16x3 MFMA kernel (4 waves, phases back to back),
+ * 2 = chunked MFMA kernel with producer/consumer wave specialisation (the default). */
 int vrwkv_wkv7_set_backward_variant(int variant);
 
 /* ---- Fused element-wise glue of RWKV_Tmix_x070 / RWKV_CMix_x070 (VisualRWKV-v7/v7.00/src/model.py), forward and
@@ -124,7 +125,7 @@ int vrwkv_wkv7_profile_bf16(int backward, int B, int T, int H, const void* w, co
 
 /* Hardware probe for the GPU tests (MFMA lane maps, cross-lane primitives); one wave.
  * which: 0 = 16x16x4 f32, 1 = 32x32x2 f32, 2 = 16x16x32 bf16, 3 = 32x32x16 bf16 (d = a*b, row-major
- * f32 operands), 4 = cross-lane primitives (a: 64 floats, d: 384 floats). */
+ * f32 operands), 4 = cross-lane primitives (a: 64 floats, d: 896 floats). */
 int vrwkv_debug_probe(int which, const float* a, const float* b, float* d, void* stream);
 
 #ifdef __cplusplus

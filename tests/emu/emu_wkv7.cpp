@@ -5,6 +5,7 @@
 #include <wkv7_chunked.h>
 #include <wkv7_chunked_bwd.h>
 #include <wkv7_fwd_v3.h>
+#include <wkv7_bwd_v3.h>
 
 extern "C" {
 
@@ -38,8 +39,10 @@ int emu_wkv7_backward_chunked(int B, int T, int H, const void* w, const void* q,
                     (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
                     (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
     static_assert(sizeof(wkv7c::LdsB) <= 160 * 1024, "LDS budget");
-    emu::launch(dim3((unsigned)(B * H)), dim3(256), [&] { wkv7c::bwd_kernel_t<false>(p); });
-    return (int)sizeof(wkv7c::LdsB);
+    static_assert(sizeof(wkv7c::LdsB3) <= 160 * 1024, "LDS budget");
+    if (getenv("EMU_BWD_V2")) emu::launch(dim3((unsigned)(B * H)), dim3(256), [&] { wkv7c::bwd_kernel_t<false>(p); });
+    else emu::launch(dim3((unsigned)(B * H)), dim3(512), [&] { wkv7c::bwd_kernel_v3<false>(p); });
+    return (int)sizeof(wkv7c::LdsB3);
 }
 
 }  // extern "C"

@@ -47,6 +47,8 @@ DEVFN uint32_t emu_wave_read(uint32_t x, int src) {
     return r;
 }
 DEVFN float lane_xor(float x, int mask) { return __uint_as_float(emu_wave_read(__float_as_uint(x), lane_id() ^ mask)); }
+DEVFN float lane_xor16(float x) { return lane_xor(x, 16); }
+DEVFN float lane_xor32(float x) { return lane_xor(x, 32); }
 DEVFN float lane_bcast(float x, int src) { return __uint_as_float(emu_wave_read(__float_as_uint(x), src)); }
 template <int K> DEVFN float dpp_shr(float x) {
     int l = lane_id();
@@ -63,6 +65,10 @@ DEVFN float lane_xor2(float x) { return lane_xor(x, 2); }
 DEVFN float lane_half_mirror(float x) { int l = lane_id(); return __uint_as_float(emu_wave_read(__float_as_uint(x), (l & ~7) | (7 - (l & 7)))); }
 DEVFN float lane_mirror(float x) { int l = lane_id(); return __uint_as_float(emu_wave_read(__float_as_uint(x), (l & ~15) | (15 - (l & 15)))); }
 
+template <int SEL> DEVFN float quad_perm(float x) {
+    int l = lane_id();
+    return __uint_as_float(emu_wave_read(__float_as_uint(x), (l & ~3) | ((SEL >> (2 * (l & 3))) & 3)));
+}
 DEVFN f32x4 quad_transpose(f32x4 x) {
     const int m = lane_id();
     const bool o1 = m & 1, o2 = m & 2;

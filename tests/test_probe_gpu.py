@@ -29,7 +29,7 @@ def test_mfma_maps(hip_lib, which, M, N, K, bf):
 
 def test_lane_primitives(hip_lib):
     x = torch.arange(64, dtype=torch.float32) * 1.5 + 1
-    d = _probe(hip_lib, 4, x.cuda(), None, (384,)).cpu().view(6, 64)
+    d = _probe(hip_lib, 4, x.cuda(), None, (896,)).cpu().view(14, 64)
     lanes = torch.arange(64)
     assert torch.equal(d[0], x.view(4, 16).sum(1, keepdim=True).expand(4, 16).reshape(64))
     assert torch.equal(d[1], x[(lanes & ~7) | (7 - (lanes & 7))])
@@ -37,3 +37,9 @@ def test_lane_primitives(hip_lib):
     assert torch.equal(d[3], x[lanes ^ 16])
     assert torch.equal(d[4], x[lanes ^ 32])
     assert torch.allclose(d[5], x.sum().expand(64))
+    assert torch.equal(d[6], x[lanes ^ 16]) and torch.equal(d[7], x[lanes ^ 32])          # permlane16/32_swap forms
+    q = lanes & 3
+    assert torch.equal(d[8], x[(lanes & ~3) | torch.tensor([0, 0, 1, 2])[q]])             # quad_perm [0,0,1,2]
+    assert torch.equal(d[9], x[(lanes & ~3) | torch.tensor([1, 2, 3, 3])[q]])             # quad_perm [1,2,3,3]
+    for k in range(4):   # quad_transpose: out[k] of lane m = in[m] of lane k of the quad
+        assert torch.equal(d[10 + k], x[(lanes & ~3) | k] + 100.0 * q)

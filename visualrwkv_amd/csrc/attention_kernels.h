@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void fwd_kernel(Args p) {
                 st[t][r] = valid ? st[t][r] * p.scale_log2e : -1e30f;
                 mx = fmaxf(mx, st[t][r]);
             }
-        mx = fmaxf(mx, lane_xor(mx, 16));
-        mx = fmaxf(mx, lane_xor(mx, 32));
+        mx = fmaxf(mx, lane_xor16(mx));
+        mx = fmaxf(mx, lane_xor32(mx));
         const float m_new = fmaxf(m_run, mx);
         const float alpha = exp2f(m_run - m_new);
         float ps = 0.f;
@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256) void fwd_kernel(Args p) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { st[t][r] = exp2f(st[t][r] - m_new); ps += st[t][r]; }
-        ps += lane_xor(ps, 16);
-        ps += lane_xor(ps, 32);
+        ps += lane_xor16(ps);
+        ps += lane_xor32(ps);
         l_run = l_run * alpha + ps;
         m_run = m_new;
         // P^T as B operand: slots e<4 <-> key 4g+e of tile 0, e>=4 <-> tile 1

@@ -69,10 +69,27 @@ DEVFN float lane_half_mirror(float x) { return dpp_mov<0x141>(x); }  // i <-> 7-
 DEVFN float lane_mirror(float x) { return dpp_mov<0x140>(x); }       // i <-> 15-i  inside each 16 lanes
 // arbitrary xor partner (ds_bpermute / permlane paths, chosen by the compiler)
 DEVFN float lane_xor(float x, int mask) { return __shfl_xor(x, mask, 64); }
+// exchange with the lane 16 / 32 away as VALU ops (v_permlane16_swap / v_permlane32_swap, gfx950) instead of
+// an LDS round trip (ds_bpermute): swap(vdst, src) exchanges vdst's odd rows (upper half) with src's even rows
+// (lower half); fed with two copies of x, the partner's value lands in result[0] for the odd/upper lanes and
+// in result[1] for the even/lower ones.
+DEVFN float lane_xor16(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float((threadIdx.x & 16) ? r[0] : r[1]);
+}
+DEVFN float lane_xor32(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
 DEVFN float lane_bcast(float x, int src_lane) { return __shfl(x, src_lane, 64); }
 DEVFN int lane_id() { return (int)(threadIdx.x & 63); }
 // value is wave-uniform by construction (e.g. threadIdx.x >> 6): make that provable -> scalar branches
 DEVFN int uniform_i32(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// arbitrary permutation inside every quad of lanes: lane m reads lane (SEL >> 2m) & 3 of its quad
+template <int SEL> DEVFN float quad_perm(float x) { return dpp_mov<SEL>(x); }
 
 // 4x4 transpose inside every quad of lanes: in: lane m (= lane&3) holds x[r], out: lane m holds x_r[m] of lane r
 // (two butterfly stages of quad_perm DPP + selects).  Turns "4 consecutive rows, one column per lane" MFMA
@@ -103,8 +120,8 @@ template <int LOG2> DEVFN float group_sum(float x) {
     if (LOG2 >= 2) x += lane_xor2(x);
     if (LOG2 >= 3) x += lane_half_mirror(x);
     if (LOG2 >= 4) x += lane_mirror(x);
-    if (LOG2 >= 5) x += lane_xor(x, 16);
-    if (LOG2 >= 6) x += lane_xor(x, 32);
+    if (LOG2 >= 5) x += lane_xor16(x);
+    if (LOG2 >= 6) x += lane_xor32(x);
     return x;
 }
 

@@ -56,6 +56,11 @@ __global__ void probe_lanes(const float* in, float* out) {
     out[192 + l] = lane_xor(x, 16);
     out[256 + l] = lane_xor(x, 32);
     out[320 + l] = group_sum<6>(x);
+    out[384 + l] = lane_xor16(x);
+    out[448 + l] = lane_xor32(x);
+    out[512 + l] = quad_perm<0x90>(x);
+    out[576 + l] = quad_perm<0xF9>(x);
+    { f32x4 v = {x, x + 100.f, x + 200.f, x + 300.f}; v = quad_transpose(v); out[640 + l] = v[0]; out[704 + l] = v[1]; out[768 + l] = v[2]; out[832 + l] = v[3]; }
 }
 
 }  // namespace

@@ -1,0 +1,400 @@
+// WKV7 backward, chunked MFMA form, producer/consumer wave specialisation -- gfx950.
+//
+// Same algorithm as wkv7_chunked_bwd.h (see its header for the math); the schedule is rebuilt from the phase
+// times measured on MI355X for the 4-wave kernel (per chunk, B=8: prep 3.4k cycles, scores 1.9k, i-split 2.4k,
+// score gradients 0.7k, j-split 2.5k, tail 1.3k, all back to back on one wave per SIMD).
+// One workgroup = 8 waves per (b,h); chunks are walked from last to first; three LDS-only barriers per chunk:
+//
+//              segment 1                    X   segment 2                         Y   segment 3            Z
+//   producers  prep(c-1), first part            prep(c-1) rest, dM(c) gradients      scores(c-1): M^T, T
+//   consumers  i-split(c): dSA dR dV, dS^T      j-split(c) products against S0/dU    + dM products, tail(c)
+//
+// Producers (waves 4..7) own all input loads of the NEXT chunk (prefetched one iteration ahead) and fill LDS
+// buffer (c-1)&1; consumers (waves 0..3) read buffer c&1, own the two register copies of dS (S^T tiles split
+// over value columns i, S tiles split over key columns j -- no cross-wave reduction anywhere) and issue all
+// stores.  For the element-wise tail the four C-layout results are bounced through a wave-private LDS strip into
+// "one token, 4 consecutive channels per lane", the raw inputs are re-read from L2 in that layout, and the decay
+// prefix / gradient suffix sums over the 16 tokens are in-row DPP scans (a register-only variant with quad
+// transposes and cross-row shuffles was measured 3x slower: 477 vs ~150 instructions).
+#pragma once
+#include <gfx950_prims.h>
+#include <wkv7_chunked_bwd.h>
+
+namespace wkv7c {
+
+struct BufB {                       // produced per chunk, double buffered
+    uint16_t ab[4][L][TJ];          // Ab_hi Ab_lo Kb_hi Kb_lo            [t][j]
+    uint16_t trn[8][N][JT];         // ZtT QtT AhT KhT (hi,lo)            [j][t]
+    uint16_t ti[4][L][TJ];          // V  dY  SA_hi  SA_lo                [t][i]
+    uint16_t dyT[N][JT];            // dY^T                               [i][t]
+    uint16_t sc[4][2][L][SS];       // M_qa^T  M_qk^T  M_zk^T  T^T  (hi,lo) A-operand images
+    float cl[N];
+};
+struct LdsB3 {
+    BufB b[2];
+    uint16_t opnd[8][L][TJ];        // producers only: Zt Qt Ah Kh (hi,lo) [t][j]
+    uint16_t dr[2][L][TJ];          // dR hi,lo    [t][i]   (consumers -> producers' dM, consumers' j-split)
+    uint16_t drT[2][N][JT];         // dR^T hi,lo  [i][t]
+    uint16_t dsc[8][2][L][SS];      // dM images (producers -> consumers)
+    float glast[N];
+    float res[4][L][N];             // dZt dQt dAh dKh bounced from C layout to "token per lane" for the tail
+};
+
+struct RawB { uint2 w, q, k, z, a, v, dy; float4 sa; };
+
+// ------------------------------------------------------------------------------------------ producers
+DEVFN void bwd_prep_a(LdsB3& lds, BufB& B, const RawB& raw, int pw, int lane, float* keep_ab, float* keep_kb) {
+    const int c16 = lane & 15, g = lane >> 4, c0 = 16 * pw + 4 * g;
+    float wr[4], q[4], k[4], z[4], a[4];
+    unpack4(raw.w, wr); unpack4(raw.q, q); unpack4(raw.k, k); unpack4(raw.z, z); unpack4(raw.a, a);
+    float zt[4], qt[4], ah[4], kh[4], cend[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float lw = -fast_exp(wr[e]);
+        float x = lw;
+        x += dpp_shr<1>(x); x += dpp_shr<2>(x); x += dpp_shr<4>(x); x += dpp_shr<8>(x);
+        const float tot = lane_bcast(x, (lane & 48) | 15);
+        const float cc = fast_exp(x), cp = fast_exp(x - lw), ic = fast_exp(-x), cb = fast_exp(tot - x);
+        zt[e] = z[e] * cp; qt[e] = q[e] * cc; ah[e] = a[e] * ic; kh[e] = k[e] * ic;
+        keep_ab[e] = a[e] * cb; keep_kb[e] = k[e] * cb; cend[e] = cc;
+    }
+    uint2 hh, ll;
+    split4(zt, hh, ll); st8(&lds.opnd[0][c16][c0], hh); st8(&lds.opnd[1][c16][c0], ll);
+    st_b16x4_T(B.trn[0], c0, c16, hh); st_b16x4_T(B.trn[1], c0, c16, ll);
+    split4(qt, hh, ll); st8(&lds.opnd[2][c16][c0], hh); st8(&lds.opnd[3][c16][c0], ll);
+    st_b16x4_T(B.trn[2], c0, c16, hh); st_b16x4_T(B.trn[3], c0, c16, ll);
+    split4(ah, hh, ll); st8(&lds.opnd[4][c16][c0], hh); st8(&lds.opnd[5][c16][c0], ll);
+    st_b16x4_T(B.trn[4], c0, c16, hh); st_b16x4_T(B.trn[5], c0, c16, ll);
+    split4(kh, hh, ll); st8(&lds.opnd[6][c16][c0], hh); st8(&lds.opnd[7][c16][c0], ll);
+    st_b16x4_T(B.trn[6], c0, c16, hh); st_b16x4_T(B.trn[7], c0, c16, ll);
+    if (c16 == 15) *reinterpret_cast<float4*>(&B.cl[c0]) = make_float4(cend[0], cend[1], cend[2], cend[3]);
+}
+DEVFN void bwd_prep_b(BufB& B, const RawB& raw, int pw, int lane, const float* ab, const float* kb) {
+    const int c16 = lane & 15, g = lane >> 4, c0 = 16 * pw + 4 * g;
+    uint2 hh, ll;
+    split4(ab, hh, ll); st8(&B.ab[0][c16][c0], hh); st8(&B.ab[1][c16][c0], ll);
+    split4(kb, hh, ll); st8(&B.ab[2][c16][c0], hh); st8(&B.ab[3][c16][c0], ll);
+    st8(&B.ti[0][c16][c0], raw.v);
+    st8(&B.ti[1][c16][c0], raw.dy);
+    st_b16x4_T(B.dyT, c0, c16, raw.dy);
+    const float sav[4] = {raw.sa.x, raw.sa.y, raw.sa.z, raw.sa.w};
+    split4(sav, hh, ll); st8(&B.ti[2][c16][c0], hh); st8(&B.ti[3][c16][c0], ll);
+}
+
+DEVFN void bwd_scores(LdsB3& lds, BufB& B, int pw, int lane) {
+    const int c16 = lane & 15, g = lane >> 4;
+    if (pw != 0) {
+        // (Qt Ah^T) / (Qt Kh^T) / (Zt Kh^T) [t][s] held as lane c16 = s, r <-> t  = A image of the transposed score
+        const int mx = pw == 3 ? 0 : 2, my = pw == 1 ? 4 : 6;
+        f32x4 d = dot64<true, true>(lds.opnd[mx], lds.opnd[mx + 1], lds.opnd[my], lds.opnd[my + 1], c16, g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[r] = (pw == 3 ? (c16 < 4 * g + r) : (c16 <= 4 * g + r)) ? d[r] : 0.f;
+        uint2 hh, ll; split4(d, hh, ll);
+        st8(&B.sc[pw - 1][0][c16][4 * g], hh); st8(&B.sc[pw - 1][1][c16][4 * g], ll);
+    } else {
+        f32x4 X = dot64<true, true>(lds.opnd[0], lds.opnd[1], lds.opnd[4], lds.opnd[5], c16, g);    // [t][s]
+        f32x4 XT = dot64<true, true>(lds.opnd[4], lds.opnd[5], lds.opnd[0], lds.opnd[1], c16, g);   // [s][t]
+        f32x4 Tc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            X[r] = (c16 < 4 * g + r) ? X[r] : 0.f;
+            XT[r] = (4 * g + r < c16) ? XT[r] : 0.f;
+            Tc[r] = X[r] + ((4 * g + r == c16) ? 1.f : 0.f);
+        }
+#pragma unroll
+        for (int level = 0; level < 3; ++level) {
+            f32x4 XTn = zero4(), Xn = X, D = zero4();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) XTn = mfma_16x16x4_f32(X[r], XT[r], XTn);        // (X^T)^2
+            if (level < 2) {
+                Xn = zero4();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Xn = mfma_16x16x4_f32(XT[r], X[r], Xn);      // X^2
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) D = mfma_16x16x4_f32(XTn[r], Tc[r], D);          // X_k T
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Tc[r] += D[r];
+            X = Xn; XT = XTn;
+        }
+        uint2 hh, ll; split4(Tc, hh, ll);                      // Tc[r] = T[4g+r][c16] = T^T[c16][4g+r]
+        st8(&B.sc[3][0][c16][4 * g], hh); st8(&B.sc[3][1][c16][4 * g], ll);
+    }
+}
+
+DEVFN void st_dsc(LdsB3& lds, int slot, f32x4 d, int c16, int g, int mode) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int x = 4 * g + r;
+        const bool keep = mode == 0 ? (c16 < x) : mode == 1 ? (x < c16) : mode == 2 ? (c16 <= x) : (x <= c16);
+        d[r] = keep ? d[r] : 0.f;
+    }
+    uint2 h, l;
+    split4(d, h, l);
+    st8(&lds.dsc[slot][0][c16][4 * g], h);
+    st8(&lds.dsc[slot][1][c16][4 * g], l);
+}
+DEVFN void bwd_dscores(LdsB3& lds, const BufB& B, int pw, int lane) {
+    const int c16 = lane & 15, g = lane >> 4;
+    if (pw == 0) {          // dM_za = tril_(dR SA^T)
+        st_dsc(lds, 1, dot64<true, true>(lds.dr[0], lds.dr[1], B.ti[2], B.ti[3], c16, g), c16, g, 0);
+        st_dsc(lds, 0, dot64<true, true>(B.ti[2], B.ti[3], lds.dr[0], lds.dr[1], c16, g), c16, g, 1);
+    } else if (pw == 1) {   // dM_zk = tril_(dR V^T)
+        st_dsc(lds, 3, dot64<true, false>(lds.dr[0], lds.dr[1], B.ti[0], B.ti[0], c16, g), c16, g, 0);
+        st_dsc(lds, 2, dot64<false, true>(B.ti[0], B.ti[0], lds.dr[0], lds.dr[1], c16, g), c16, g, 1);
+    } else if (pw == 2) {   // dM_qa = tril(dY SA^T)
+        st_dsc(lds, 5, dot64<false, true>(B.ti[1], B.ti[1], B.ti[2], B.ti[3], c16, g), c16, g, 2);
+        st_dsc(lds, 4, dot64<true, false>(B.ti[2], B.ti[3], B.ti[1], B.ti[1], c16, g), c16, g, 3);
+    } else {                // dM_qk = tril(dY V^T)
+        st_dsc(lds, 7, dot64<false, false>(B.ti[1], B.ti[1], B.ti[0], B.ti[0], c16, g), c16, g, 2);
+        st_dsc(lds, 6, dot64<false, false>(B.ti[0], B.ti[0], B.ti[1], B.ti[1], c16, g), c16, g, 3);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ kernel
+template <bool PROF>
+__global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
+    LdsB3& lds = *reinterpret_cast<LdsB3*>(dyn_lds());
+    const int T = p.T, H = p.H;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = uniform_i32(tid >> 6);
+    const int c16 = lane & 15, g = lane >> 4;
+    const int nchunk = T / L;
+    const unsigned ts = (unsigned)(H * N);
+    const size_t head_base = ((size_t)(blockIdx.x / H) * T * H + (blockIdx.x % H)) * N;
+    WKV_STAMP_DECL
+
+    if (wave >= 4) {
+        // ================================================================== producers
+        const int pw = wave - 4;
+        const unsigned lane_off = (unsigned)c16 * ts + 16u * pw + 4u * g;
+        auto fetch = [&](RawB& r, int c) {
+            const size_t o = head_base + (size_t)c * L * ts + lane_off;
+            r.w = *reinterpret_cast<const uint2*>(p.w + o); r.q = *reinterpret_cast<const uint2*>(p.q + o);
+            r.k = *reinterpret_cast<const uint2*>(p.k + o); r.z = *reinterpret_cast<const uint2*>(p.z + o);
+            r.a = *reinterpret_cast<const uint2*>(p.a + o); r.v = *reinterpret_cast<const uint2*>(p.v + o);
+            r.dy = *reinterpret_cast<const uint2*>(p.dy + o); r.sa = *reinterpret_cast<const float4*>(p.sa + o);
+        };
+        RawB raw;
+        fetch(raw, nchunk - 1);
+        // prologue: produce the last chunk completely (prep + scores); consumers idle through X,Y,Z
+        {
+            float kab[4], kkb[4];
+            RawB cur = raw;
+            if (nchunk > 1) fetch(raw, nchunk - 2);
+            bwd_prep_a(lds, lds.b[(nchunk - 1) & 1], cur, pw, lane, kab, kkb);
+            bwd_prep_b(lds.b[(nchunk - 1) & 1], cur, pw, lane, kab, kkb);
+            block_sync_lds();   // X
+            block_sync_lds();   // Y
+            bwd_scores(lds, lds.b[(nchunk - 1) & 1], pw, lane);
+            block_sync_lds();   // Z
+        }
+        for (int c = nchunk - 1; c >= 0; --c) {      // consumers process chunk c, producers build chunk c-1
+            const bool more = c > 0;
+            float kab[4], kkb[4];
+            RawB cur = raw;
+            if (more) {
+                if (c > 1) fetch(raw, c - 2);
+                bwd_prep_a(lds, lds.b[(c - 1) & 1], cur, pw, lane, kab, kkb);
+            }
+            WKV_STAMP(0)
+            block_sync_lds();   // X : consumers' dR(c) is in LDS
+            WKV_STAMP(1)
+            if (more) bwd_prep_b(lds.b[(c - 1) & 1], cur, pw, lane, kab, kkb);
+            bwd_dscores(lds, lds.b[c & 1], pw, lane);
+            WKV_STAMP(2)
+            block_sync_lds();   // Y : dM(c) images ready for the consumers
+            WKV_STAMP(3)
+            if (more) bwd_scores(lds, lds.b[(c - 1) & 1], pw, lane);
+            WKV_STAMP(4)
+            block_sync_lds();   // Z
+            WKV_STAMP(5)
+        }
+        WKV_STAMP_FLUSH(256, 8, 6)
+        return;
+    }
+
+    // ====================================================================== consumers
+    const float* sbase = p.s + (size_t)blockIdx.x * nchunk * N * N;
+    f32x4 dS1[4], dS2[4], SL[4], S0n[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { dS1[x] = zero4(); dS2[x] = zero4(); }
+    auto load_state = [&](f32x4* dst, int cidx) {      // s[cidx] as S[i][j] tiles: [ib][r] = S[16ib+4g+r][16w+c16]
+        const float* sp = sbase + (size_t)cidx * N * N + (size_t)(16 * wave + c16) * N + 4 * g;
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            const float4 x = *reinterpret_cast<const float4*>(sp + 16 * ib);
+            dst[ib][0] = x.x; dst[ib][1] = x.y; dst[ib][2] = x.z; dst[ib][3] = x.w;
+        }
+    };
+    load_state(SL, nchunk - 1);
+    if (nchunk > 1) load_state(S0n, nchunk - 2);
+    else {
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) S0n[ib] = zero4();
+    }
+    // tail layout: lane (t = c16, g) <-> token c16, channels 16w + 4g .. +3 (in-row DPP scans over the 16 tokens)
+    const int c0 = 16 * wave + 4 * g;
+    const unsigned row_off = (unsigned)c16 * ts + (unsigned)c0;
+    const unsigned dv_off = (unsigned)(4 * g) * ts + 16u * wave + c16;
+
+    block_sync_lds(); block_sync_lds(); block_sync_lds();      // prologue X, Y, Z
+    for (int c = nchunk - 1; c >= 0; --c) {
+        const BufB& B = lds.b[c & 1];
+        const size_t cbase = head_base + (size_t)c * L * ts;
+        // ---------------------------------------------------------------- segment 1: i-split (i = 16w + c16)
+        uint2 rh, rl;
+        const uint2 dy = ld8(&B.dyT[16 * wave + c16][4 * g]);
+        {
+            bf16x8 bh[2], bl[2];
+            tiles_to_b(dS1, 1.f, bh, bl);
+            f32x4 dSA = mm_small_exact(zero4(), B.sc[0][0], B.sc[0][1], c16, g, dy);                // M_qa^T dY
+            dSA = mm_perm<true>(dSA, B.ab[0], B.ab[1], c16, g, bh, bl);                             // Ab dS^T
+            uint2 xh, xl;
+            split4(dSA, xh, xl);
+            const f32x4 dR = mm_small(zero4(), B.sc[3][0], B.sc[3][1], c16, g, xh, xl);             // T^T dSA
+            split4(dR, rh, rl);
+            f32x4 dV = mm_small_exact(zero4(), B.sc[1][0], B.sc[1][1], c16, g, dy);                 // M_qk^T dY
+            dV = mm_perm<true>(dV, B.ab[2], B.ab[3], c16, g, bh, bl);                               // Kb dS^T
+            dV = mm_small(dV, B.sc[2][0], B.sc[2][1], c16, g, rh, rl);                              // M_zk^T dR
+            st_b16x4_col(lds.dr[0], 4 * g, 16 * wave + c16, rh);
+            st_b16x4_col(lds.dr[1], 4 * g, 16 * wave + c16, rl);
+            st8(&lds.drT[0][16 * wave + c16][4 * g], rh);
+            st8(&lds.drT[1][16 * wave + c16][4 * g], rl);
+            uint16_t* dvp = p.dv + cbase;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dvp[dv_off + r * ts] = (uint16_t)f32_to_bf16_bits(dV[r]);
+            // dS^T <- diag(c_L) dS^T + [Qt^T | Zt^T] [dY ; dR]
+            const bf16x8 b1 = mk8(dy, rh), b2 = mk8(0u, 0u, rl.x, rl.y);
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                const float4 cl = *reinterpret_cast<const float4*>(&B.cl[16 * jb + 4 * g]);
+                f32x4 acc = dS1[jb];
+                acc[0] *= cl.x; acc[1] *= cl.y; acc[2] *= cl.z; acc[3] *= cl.w;
+                const int j = 16 * jb + c16;
+                const bf16x8 ah = mk8(ld8(&B.trn[2][j][4 * g]), ld8(&B.trn[0][j][4 * g]));
+                const bf16x8 al = mk8(ld8(&B.trn[3][j][4 * g]), ld8(&B.trn[1][j][4 * g]));
+                acc = mfma_16x16x32_bf16(ah, b1, acc);
+                acc = mfma_16x16x32_bf16(ah, b2, acc);
+                acc = mfma_16x16x32_bf16(al, b1, acc);
+                dS1[jb] = acc;
+            }
+        }
+        WKV_STAMP(0)
+        block_sync_lds();       // X
+        WKV_STAMP(1)
+        // ---------------------------------------------------------------- segment 2: j-split against S0 / dU (j = 16w + c16)
+        const int j = 16 * wave + c16;
+        const float clj = B.cl[j];
+        f32x4 S0[4];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) S0[ib] = S0n[ib];
+        if (c > 1) load_state(S0n, c - 2);
+        else {
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) S0n[ib] = zero4();
+        }
+        // raw inputs of this chunk in row layout for the tail (L2 hits: the producers read them two chunks ago)
+        const uint2 tw = *reinterpret_cast<const uint2*>(p.w + cbase + row_off);
+        const uint2 tq = *reinterpret_cast<const uint2*>(p.q + cbase + row_off);
+        const uint2 tk = *reinterpret_cast<const uint2*>(p.k + cbase + row_off);
+        const uint2 tz = *reinterpret_cast<const uint2*>(p.z + cbase + row_off);
+        const uint2 ta = *reinterpret_cast<const uint2*>(p.a + cbase + row_off);
+        const uint2 zth = ld8(&B.trn[0][j][4 * g]), ztl = ld8(&B.trn[1][j][4 * g]);
+        const uint2 qth = ld8(&B.trn[2][j][4 * g]), qtl = ld8(&B.trn[3][j][4 * g]);
+        f32x4 dZt, dQt, dAh, dKh;
+        float gl = 0.f;
+        {
+            bf16x8 s0h[2], s0l[2], duh[2], dul[2];
+            tiles_to_b(S0, 1.f, s0h, s0l);
+            tiles_to_b(dS2, clj, duh, dul);
+            dZt = mm_perm<true>(zero4(), lds.dr[0], lds.dr[1], c16, g, s0h, s0l);                  // dR S0
+            dQt = mm_perm<false>(zero4(), B.ti[1], B.ti[1], c16, g, s0h, s0l);                     // dY S0
+            dAh = mm_perm<true>(zero4(), B.ti[2], B.ti[3], c16, g, duh, dul);                      // SA dU
+            dKh = mm_perm<false>(zero4(), B.ti[0], B.ti[0], c16, g, duh, dul);                     // V dU
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gl = fmaf(dS2[ib][r], SL[ib][r], gl);
+            gl += lane_xor16(gl);
+            gl += lane_xor32(gl);
+            if (g == 0) lds.glast[j] = gl;
+            // dS <- dS diag(c_L) + [dY^T | dR^T] [Qt ; Zt]
+            const bf16x8 bqh = mk8(qth, zth), bql = mk8(qtl, ztl);
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) {
+                f32x4 acc = dS2[ib];
+                acc[0] *= clj; acc[1] *= clj; acc[2] *= clj; acc[3] *= clj;
+                const int i = 16 * ib + c16;
+                const bf16x8 ah = mk8(ld8(&B.dyT[i][4 * g]), ld8(&lds.drT[0][i][4 * g]));
+                const uint2 rl2 = ld8(&lds.drT[1][i][4 * g]);
+                acc = mfma_16x16x32_bf16(ah, bqh, acc);
+                acc = mfma_16x16x32_bf16(ah, bql, acc);
+                acc = mfma_16x16x32_bf16(mk8(0u, 0u, rl2.x, rl2.y), bqh, acc);
+                dS2[ib] = acc;
+                SL[ib] = S0[ib];
+            }
+        }
+        WKV_STAMP(2)
+        block_sync_lds();       // Y
+        WKV_STAMP(3)
+        // ---------------------------------------------------------------- segment 3: dM products + tail
+        {
+            const uint2 ahh = ld8(&B.trn[4][j][4 * g]), ahl = ld8(&B.trn[5][j][4 * g]);
+            const uint2 khh = ld8(&B.trn[6][j][4 * g]), khl = ld8(&B.trn[7][j][4 * g]);
+            dZt = mm_small(dZt, lds.dsc[0][0], lds.dsc[0][1], c16, g, ahh, ahl);                    // dM_za Ah
+            dZt = mm_small(dZt, lds.dsc[2][0], lds.dsc[2][1], c16, g, khh, khl);                    // dM_zk Kh
+            dQt = mm_small(dQt, lds.dsc[4][0], lds.dsc[4][1], c16, g, ahh, ahl);                    // dM_qa Ah
+            dQt = mm_small(dQt, lds.dsc[6][0], lds.dsc[6][1], c16, g, khh, khl);                    // dM_qk Kh
+            dAh = mm_small(dAh, lds.dsc[1][0], lds.dsc[1][1], c16, g, zth, ztl);                    // dM_za^T Zt
+            dAh = mm_small(dAh, lds.dsc[5][0], lds.dsc[5][1], c16, g, qth, qtl);                    // dM_qa^T Qt
+            dKh = mm_small(dKh, lds.dsc[3][0], lds.dsc[3][1], c16, g, zth, ztl);                    // dM_zk^T Zt
+            dKh = mm_small(dKh, lds.dsc[7][0], lds.dsc[7][1], c16, g, qth, qtl);                    // dM_qk^T Qt
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            lds.res[0][4 * g + r][j] = dZt[r];
+            lds.res[1][4 * g + r][j] = dQt[r];
+            lds.res[2][4 * g + r][j] = dAh[r];
+            lds.res[3][4 * g + r][j] = dKh[r];
+        }
+        wave_lds_fence();           // res columns [16w,16w+16) and glast are written and read by this wave only
+        {
+            const float4 rz = *reinterpret_cast<const float4*>(&lds.res[0][c16][c0]);
+            const float4 rq = *reinterpret_cast<const float4*>(&lds.res[1][c16][c0]);
+            const float4 ra = *reinterpret_cast<const float4*>(&lds.res[2][c16][c0]);
+            const float4 rk = *reinterpret_cast<const float4*>(&lds.res[3][c16][c0]);
+            const float4 gl4 = *reinterpret_cast<const float4*>(&lds.glast[c0]);
+            const float dzt[4] = {rz.x, rz.y, rz.z, rz.w}, dqt[4] = {rq.x, rq.y, rq.z, rq.w};
+            const float dah[4] = {ra.x, ra.y, ra.z, ra.w}, dkh[4] = {rk.x, rk.y, rk.z, rk.w};
+            const float glv[4] = {gl4.x, gl4.y, gl4.z, gl4.w};
+            float wr[4], q[4], k[4], z[4], a[4];
+            unpack4(tw, wr); unpack4(tq, q); unpack4(tk, k); unpack4(tz, z); unpack4(ta, a);
+            float dz[4], dq[4], da[4], dk[4], dw[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lw = -fast_exp(wr[e]);
+                float x = lw;
+                x += dpp_shr<1>(x); x += dpp_shr<2>(x); x += dpp_shr<4>(x); x += dpp_shr<8>(x);
+                const float cc = fast_exp(x), cp = fast_exp(x - lw), ic = fast_exp(-x);
+                dz[e] = dzt[e] * cp; dq[e] = dqt[e] * cc; da[e] = dah[e] * ic; dk[e] = dkh[e] * ic;
+                float gt = dq[e] * q[e] - da[e] * a[e] - dk[e] * k[e] + dpp_shl<1>(dz[e] * z[e]);
+                if (c16 == 15) gt += glv[e];
+                gt += dpp_shl<1>(gt); gt += dpp_shl<2>(gt); gt += dpp_shl<4>(gt); gt += dpp_shl<8>(gt);   // suffix sum over t
+                dw[e] = gt * lw;
+            }
+            const size_t o = cbase + row_off;
+            *reinterpret_cast<uint2*>(p.dw + o) = make_uint2(cvt_pk_bf16(dw[0], dw[1]), cvt_pk_bf16(dw[2], dw[3]));
+            *reinterpret_cast<uint2*>(p.dq + o) = make_uint2(cvt_pk_bf16(dq[0], dq[1]), cvt_pk_bf16(dq[2], dq[3]));
+            *reinterpret_cast<uint2*>(p.dk + o) = make_uint2(cvt_pk_bf16(dk[0], dk[1]), cvt_pk_bf16(dk[2], dk[3]));
+            *reinterpret_cast<uint2*>(p.dz + o) = make_uint2(cvt_pk_bf16(dz[0], dz[1]), cvt_pk_bf16(dz[2], dz[3]));
+            *reinterpret_cast<uint2*>(p.da + o) = make_uint2(cvt_pk_bf16(da[0], da[1]), cvt_pk_bf16(da[2], da[3]));
+        }
+        WKV_STAMP(4)
+        block_sync_lds();       // Z
+        WKV_STAMP(5)
+    }
+    WKV_STAMP_FLUSH(0, 0, 6)
+}
+
+}  // namespace wkv7c

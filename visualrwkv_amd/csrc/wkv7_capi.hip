@@ -7,6 +7,7 @@
 #include <wkv7_chunked.h>
 #include <wkv7_chunked_bwd.h>
 #include <wkv7_fwd_v3.h>
+#include <wkv7_bwd_v3.h>
 
 namespace {
 
@@ -49,7 +50,7 @@ int vrwkv_wkv7_set_forward_variant(int variant) {
 }
 
 int vrwkv_wkv7_set_backward_variant(int variant) {
-    if (variant > 1) return VRWKV_EINVAL;
+    if (variant > 2) return VRWKV_EINVAL;
     g_bwd_variant = variant;
     return VRWKV_OK;
 }
@@ -109,6 +110,15 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H, const void* w, const void* q, 
     const dim3 grid((unsigned)((long)B * H));
     if (g_bwd_variant == 0) {
         hipLaunchKernelGGL((wkv7::bwd_kernel<8>), grid, dim3(256), 0, st, p);
+    } else if (g_bwd_variant < 0 || g_bwd_variant == 2) {
+        static bool attr3_set = false;
+        if (!attr3_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::bwd_kernel_v3<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsB3));
+            if (e != hipSuccess) return (int)e;
+            attr3_set = true;
+        }
+        hipLaunchKernelGGL(wkv7c::bwd_kernel_v3<false>, grid, dim3(512), sizeof(wkv7c::LdsB3), st, p);
     } else {
         static bool attr_set = false;     // > 64 KB of LDS needs the opt-in once per process
         if (!attr_set) {
@@ -148,10 +158,17 @@ int vrwkv_wkv7_profile_bf16(int backward, int B, int T, int H, const void* w, co
         wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                         (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
                         (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da, dbg};
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::bwd_kernel_t<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsB));
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(wkv7c::bwd_kernel_t<true>, grid, dim3(256), sizeof(wkv7c::LdsB), st, p);
+        if (g_bwd_variant == 1) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::bwd_kernel_t<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsB));
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(wkv7c::bwd_kernel_t<true>, grid, dim3(256), sizeof(wkv7c::LdsB), st, p);
+        } else {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::bwd_kernel_v3<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsB3));
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(wkv7c::bwd_kernel_v3<true>, grid, dim3(512), sizeof(wkv7c::LdsB3), st, p);
+        }
     }
     return finish_launch();
 }

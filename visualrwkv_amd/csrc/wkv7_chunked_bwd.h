@@ -355,8 +355,8 @@ __global__ __launch_bounds__(256) void bwd_kernel_t(BwdArgs p) {
             for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gl = fmaf(dS2[ib][r], SL[ib][r], gl);
-            gl += lane_xor(gl, 16);
-            gl += lane_xor(gl, 32);
+            gl += lane_xor16(gl);
+            gl += lane_xor32(gl);
             if (g == 0) lds.glast[j] = gl;
 
             // dS <- dS diag(c_L) + [dY^T | dR^T] [Qt ; Zt]

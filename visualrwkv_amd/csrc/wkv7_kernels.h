@@ -337,11 +337,11 @@ __global__ __launch_bounds__(256) void bwd_kernel(BwdArgs p) {
             // sum the column partials over the wave's 4 row groups (lane bits 4,5)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                pdw[j] += lane_xor(pdw[j], 16); pdw[j] += lane_xor(pdw[j], 32);
-                pdq[j] += lane_xor(pdq[j], 16); pdq[j] += lane_xor(pdq[j], 32);
-                pdk[j] += lane_xor(pdk[j], 16); pdk[j] += lane_xor(pdk[j], 32);
-                pda[j] += lane_xor(pda[j], 16); pda[j] += lane_xor(pda[j], 32);
-                pdz[j] += lane_xor(pdz[j], 16); pdz[j] += lane_xor(pdz[j], 32);
+                pdw[j] += lane_xor16(pdw[j]); pdw[j] += lane_xor32(pdw[j]);
+                pdq[j] += lane_xor16(pdq[j]); pdq[j] += lane_xor32(pdq[j]);
+                pdk[j] += lane_xor16(pdk[j]); pdk[j] += lane_xor32(pdk[j]);
+                pda[j] += lane_xor16(pda[j]); pda[j] += lane_xor32(pda[j]);
+                pdz[j] += lane_xor16(pdz[j]); pdz[j] += lane_xor32(pdz[j]);
             }
             if (rg == 0) {
                 *reinterpret_cast<float4*>(&part[s][0][wave][col0]) = make_float4(pdw[0], pdw[1], pdw[2], pdw[3]);
