@@ -40,18 +40,26 @@ DEVFN void put_partial(float* part, int nvec, int vec, int C, int c0, const V8& 
     *reinterpret_cast<float4*>(dst) = make_float4(v.f[0], v.f[1], v.f[2], v.f[3]);
     *reinterpret_cast<float4*>(dst + 4) = make_float4(v.f[4], v.f[5], v.f[6], v.f[7]);
 }
-// out[j] = sum_g part[g][j]
+// out[j] = sum_g part[g][j].  A workgroup owns 64 columns; thread (cq = tid & 15, rg = tid >> 4) sums rows
+// rg, rg+16, ... of 4 adjacent columns (float4), then the 16 row-groups are combined through LDS in a fixed
+// order (deterministic).  width % 64 == 0.
 __global__ __launch_bounds__(256) void colsum_kernel(int G, long width, const float* __restrict__ part, float* __restrict__ out) {
-    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= width) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int g = 0;
-    for (; g + 3 < G; g += 4) {
-        a0 += part[(size_t)g * width + j]; a1 += part[(size_t)(g + 1) * width + j];
-        a2 += part[(size_t)(g + 2) * width + j]; a3 += part[(size_t)(g + 3) * width + j];
+    __shared__ float4 red[16][16];
+    const int cq = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const long col = (long)blockIdx.x * 64 + 4 * cq;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = rg; g < G; g += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(part + (size_t)g * width + col);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
-    for (; g < G; ++g) a0 += part[(size_t)g * width + j];
-    out[j] = (a0 + a1) + (a2 + a3);
+    red[rg][cq] = a;
+    __syncthreads();
+    if (rg == 0) {
+        float4 t = red[0][cq];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) { const float4 v = red[r][cq]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        *reinterpret_cast<float4*>(out + col) = t;
+    }
 }
 DEVFN float sigmoidf_(float x) { return 1.f / (1.f + fast_exp(-x)); }
 
@@ -87,6 +95,9 @@ __global__ void mix_fwd_kernel(long ntok, int T, int C, const uint16_t* __restri
     }
 }
 
+// dx[n] = sum_m d_m[n] (1 - mu_m) + [t < T-1] sum_m d_m[n+1] mu_m ;  dmu_m += d_m[n] * (x[n-1] - x[n]).
+// Every token is independent (row n+1 is re-read, it is an L2/L1 hit); a variant that carried row n in registers
+// to read each row once measured 1.7x SLOWER -- the loop-carried state removes the memory-level parallelism.
 template <int M>
 __global__ void mix_bwd_kernel(long ntok, int T, int C, const uint16_t* __restrict__ x, Ptrs6 mu, Ptrs6 dout,
                                uint16_t* __restrict__ dx, float* __restrict__ dmu) {
@@ -94,35 +105,30 @@ __global__ void mix_bwd_kernel(long ntok, int T, int C, const uint16_t* __restri
     V8 m[M], gm[M];
 #pragma unroll
     for (int i = 0; i < M; ++i) { m[i] = ld8f(mu.p[i] + c0); gm[i] = zero8(); }
-    for (long nb = (long)blockIdx.x * TPB; nb < ntok; nb += (long)gridDim.x * TPB)
-    for (long n = nb; n < nb + TPB && n < ntok; ++n) {
-        const int t = (int)(n % T);
-        const V8 xv = ld8f(x + n * C + c0);
-        V8 xx, acc = zero8();
-        if (t != 0) {
-            const V8 xp = ld8f(x + (n - 1) * C + c0);
+    for (long nb = (long)blockIdx.x * TPB; nb < ntok; nb += (long)gridDim.x * TPB) {
+        const long ne = nb + TPB < ntok ? nb + TPB : ntok;
+#pragma unroll 2
+        for (long n = nb; n < ne; ++n) {
+            const int t = (int)(n % T);
+            const V8 xv = ld8f(x + n * C + c0);
+            const V8 xp = ld8f(x + (t != 0 ? n - 1 : n) * C + c0);
+            const bool has_next = t != T - 1;
+            const long nn = has_next ? n + 1 : n;
+            V8 acc = zero8();
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xx.f[e] = xp.f[e] - xv.f[e];
-        } else {
+            for (int j = 0; j < M; ++j) {
+                const V8 d = ld8f(dout.p[j] + n * C + c0);
+                const V8 dn = ld8f(dout.p[j] + nn * C + c0);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xx.f[e] = -xv.f[e];
-        }
-        const bool has_next = t != T - 1;
-#pragma unroll
-        for (int j = 0; j < M; ++j) {
-            const V8 d = ld8f(dout.p[j] + n * C + c0);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                acc.f[e] = fmaf(d.f[e], 1.f - m[j].f[e], acc.f[e]);
-                gm[j].f[e] = fmaf(d.f[e], xx.f[e], gm[j].f[e]);
+                for (int e = 0; e < 8; ++e) {
+                    const float xx = (t != 0 ? xp.f[e] : 0.f) - xv.f[e];
+                    acc.f[e] = fmaf(d.f[e], 1.f - m[j].f[e], acc.f[e]);
+                    acc.f[e] = fmaf(has_next ? dn.f[e] : 0.f, m[j].f[e], acc.f[e]);
+                    gm[j].f[e] = fmaf(d.f[e], xx, gm[j].f[e]);
+                }
             }
-            if (has_next) {
-                const V8 dn = ld8f(dout.p[j] + (n + 1) * C + c0);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc.f[e] = fmaf(dn.f[e], m[j].f[e], acc.f[e]);
-            }
+            st8f(dx + n * C + c0, acc);
         }
-        st8f(dx + n * C + c0, acc);
     }
 #pragma unroll
     for (int j = 0; j < M; ++j) put_partial(dmu, M, j, C, c0, gm[j]);
@@ -141,7 +147,7 @@ __global__ void decay_fwd_kernel(long ntok, int C, const uint16_t* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float u = hv.f[e] + b.f[e];
-            const float sp = fmaxf(-u, 0.f) + log1pf(fast_exp(-fabsf(u)));   // softplus(-u)
+            const float sp = fmaxf(-u, 0.f) + fast_log(1.f + fast_exp(-fabsf(u)));   // softplus(-u)
             o.f[e] = -sp - 0.5f;
         }
         st8f(w + n * C + c0, o);
@@ -383,7 +389,7 @@ inline dim3 tok_grid(long ntok) { return dim3((unsigned)((ntok + TPB - 1) / TPB)
 constexpr int BWD_GRID = 1024;         // workgroups (= partial rows) of the backward kernels: 4 per CU
 inline int bwd_grid(long ntok) { long g = (ntok + TPB - 1) / TPB; return (int)(g < BWD_GRID ? g : BWD_GRID); }
 inline void colsum(int G, long width, const float* part, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((width + 255) / 256)), dim3(256), 0, st, G, width, part, out);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)(width / 64)), dim3(256), 0, st, G, width, part, out);
 }
 inline int done() { hipError_t e = hipGetLastError(); return e == hipSuccess ? VRWKV_OK : (int)e; }
 
