@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--model", default="1b5", choices=list(MODELS))
-    ap.add_argument("--micro-bsz", type=int, default=8)
+    ap.add_argument("--micro-bsz", type=int, default=16)      # 210 GB of the 288 GB HBM3E, no recompute
     ap.add_argument("--ctx-len", type=int, default=2624)          # 576 image + 2048 text tokens
     ap.add_argument("--img-tokens", type=int, default=576)
     ap.add_argument("--towers", default="dino,siglip")
@@ -171,7 +171,8 @@ def main():
             "config": {"workload": f"VisualRWKV-7 {a.model} + {'+'.join(towers)} ViT, {a.img_tokens} img + {a.ctx_len - a.img_tokens} text tokens, "
                                    f"full train step (fwd+bwd+ZeRO-1 AdamW)", "model": f"VisualRWKV-7 {a.model}",
                        "global_batch": world * a.micro_bsz, "seq_len": a.ctx_len, "parallelism": f"dp{world}",
-                       "grad_cp": a.grad_cp, "fused_elementwise": bool(a.fused), "loss": float(loss.detach())},
+                       "grad_cp": a.grad_cp, "fused_elementwise": bool(a.fused), "loss": float(loss.detach()),
+                       "micro_bsz": a.micro_bsz, "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1)},
         }
         # roofline of the dominant hot-path kernel (WKV7 backward), HIP events on the launch stream
         kinds = {}
