@@ -7,6 +7,7 @@ timeout 600 python bench.py --steps 5 --warmup 2 2>&1 | grep -v amdgpu.ids | tai
 cd /tmp; export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/step -o step -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/step.log 2>&1
 cd $R
+bash benchmarks/wkv7_pmc.sh 16 gpurun_out/$TAG/pmc_b16 -1 > $O/wkv7_pmc_b16.txt 2>&1
 bash benchmarks/wkv7_pmc.sh 8 gpurun_out/$TAG/pmc_b8 -1 > $O/wkv7_pmc_b8.txt 2>&1
 python benchmarks/wkv7_micro.py --B 8 16 32 --iters 20 2>&1 | grep -v amdgpu > $O/wkv7_micro.jsonl
 cat $O/pytest_gpu.txt; cut -c1-600 $O/bench.json

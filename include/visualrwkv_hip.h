@@ -50,6 +50,12 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H,
                              void* dw, void* dq, void* dk, void* dv, void* dz, void* da,
                              void* stream);
 
+/* WKV7 single-token step with carried state (stateful generation; the reference re-runs the whole forward per new
+ * token, VisualRWKV-v7/v7.00/src/model.py:513-529).  w..a, y: (B,H,64) bf16; state: (B,H,64,64) f32, S[i][j] with
+ * i = value row, j = key column, updated in place.  (The training op's checkpoint `s` holds S^T.) */
+int vrwkv_wkv7_step_bf16(int B, int H, const void* w, const void* q, const void* k, const void* v,
+                         const void* z, const void* a, float* state, void* y, void* stream);
+
 /* Launch-shape override for benchmarking/tests: variant < 0 restores the automatic choice.
  * forward variants: 0/1/2 = sequential VALU kernel with 1/2/4 waves per head, 3 = chunked bf16x3 MFMA kernel
  * (4 waves, phases back to back), 4..7 = chunked MFMA kernel with producer/consumer wave specialisation

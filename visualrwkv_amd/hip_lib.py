@@ -18,6 +18,7 @@ PROTOTYPES = {
     "vrwkv_strerror": (ctypes.c_char_p, [_c_int]),
     "vrwkv_wkv7_forward_bf16": (_c_int, [_c_int] * 3 + [_c_void_p] * 10),
     "vrwkv_wkv7_backward_bf16": (_c_int, [_c_int] * 3 + [_c_void_p] * 16),
+    "vrwkv_wkv7_step_bf16": (_c_int, [_c_int] * 2 + [_c_void_p] * 9),
     "vrwkv_wkv7_set_forward_variant": (_c_int, [_c_int]),
     "vrwkv_wkv7_set_backward_variant": (_c_int, [_c_int]),
     "vrwkv_mix_fwd_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int, _c_int] + [_c_void_p] * 4),

@@ -100,13 +100,18 @@ class RWKV_Tmix_x070(nn.Module):
             self.value.weight.data.uniform_(-0.5 / (C ** 0.5), 0.5 / (C ** 0.5))
             self.output.weight.data.zero_()
 
-    def forward(self, x, v_first):
+    def forward(self, x, v_first, state=None):
+        """`state` (an RWKV7State, inference only) carries the previous token and the WKV state across calls."""
         B, T, C = x.size()
         H = self.n_head
-        if getattr(self.args, "fused", False) and x.is_cuda:
+        if state is None and getattr(self.args, "fused", False) and x.is_cuda:
             from . import fused
             return fused.tmix_forward(self, x, v_first)
-        xx = time_shift(x) - x
+        if state is None:
+            xx = time_shift(x) - x
+        else:
+            xx = torch.cat((state.att_x[self.layer_id].unsqueeze(1), x[:, :-1]), dim=1) - x
+            state.att_x[self.layer_id] = x[:, -1]
         xr = x + xx * self.x_r
         xw = x + xx * self.x_w
         xk = x + xx * self.x_k
@@ -129,7 +134,10 @@ class RWKV_Tmix_x070(nn.Module):
         kk = F.normalize(kk.view(B, T, H, -1), dim=-1, p=2.0).view(B, T, C)
         k = k * (1 + (a - 1) * self.k_a)
 
-        x = RUN_CUDA_RWKV7g(r, w, k, v, -kk, kk * a)
+        if state is None:
+            x = RUN_CUDA_RWKV7g(r, w, k, v, -kk, kk * a)
+        else:
+            x = state.wkv(self.layer_id, r, w, k, v, -kk, kk * a)
         x = self.ln_x(x.view(B * T, C)).view(B, T, C)
         x = x + ((r.view(B, T, H, -1) * k.view(B, T, H, -1) * self.r_k).sum(dim=-1, keepdim=True)
                  * v.view(B, T, H, -1)).view(B, T, C)
@@ -154,11 +162,15 @@ class RWKV_CMix_x070(nn.Module):
         self.key.weight.data.uniform_(-0.5 / (C ** 0.5), 0.5 / (C ** 0.5))
         self.value.weight.data.zero_()
 
-    def forward(self, x):
-        if getattr(self.args, "fused", False) and x.is_cuda:
+    def forward(self, x, state=None):
+        if state is None and getattr(self.args, "fused", False) and x.is_cuda:
             from . import fused
             return fused.cmix_forward(self, x)
-        xx = time_shift(x) - x
+        if state is None:
+            xx = time_shift(x) - x
+        else:
+            xx = torch.cat((state.ffn_x[self.layer_id].unsqueeze(1), x[:, :-1]), dim=1) - x
+            state.ffn_x[self.layer_id] = x[:, -1]
         k = x + xx * self.x_k
         k = torch.relu(self.key(k)) ** 2
         return self.value(k)
@@ -178,12 +190,17 @@ class Block(nn.Module):
         self.att = RWKV_Tmix_x070(args, layer_id)
         self.ffn = RWKV_CMix_x070(args, layer_id)
 
-    def forward(self, x, v_first):
+    def forward(self, x, v_first, state=None):
         if self.layer_id == 0:
             x = self.ln0(x)
-        xx, v_first = self.att(self.ln1(x), v_first)
-        x = x + xx
-        x = x + self.ffn(self.ln2(x))
+        if state is None:
+            xx, v_first = self.att(self.ln1(x), v_first)
+            x = x + xx
+            x = x + self.ffn(self.ln2(x))
+        else:
+            xx, v_first = self.att(self.ln1(x), v_first, state)
+            x = x + xx
+            x = x + self.ffn(self.ln2(x), state)
         return x, v_first
 
 
@@ -204,6 +221,37 @@ class L2Wrap(torch.autograd.Function):
         gy = torch.zeros_like(y)
         gy.scatter_(-1, ids, maxx * factor)
         return grad_output, gy
+
+
+class RWKV7State:
+    """Recurrent state of an RWKV-7 stack for stateful generation (the reference re-runs the
+    whole sequence per generated token, src/model.py:513-529).  Per layer: the last token fed to the time-mix and
+    channel-mix shifts (the reference's ZeroPad2d shift sees zeros before the first token) and the WKV state
+    S (B,H,64,64) fp32.  While a layer's S is still zero ("fresh"), whole 16-token chunks go through the training
+    forward kernel and only the ragged tail is stepped; afterwards every token is one `wkv7_step` launch."""
+
+    def __init__(self, args, batch, device, dtype=torch.bfloat16):
+        L, C = args.n_layer, args.n_embd
+        self.att_x = [torch.zeros(batch, C, device=device, dtype=dtype) for _ in range(L)]
+        self.ffn_x = [torch.zeros(batch, C, device=device, dtype=dtype) for _ in range(L)]
+        self.S = [torch.zeros(batch, args.dim_att // 64, 64, 64, device=device, dtype=torch.float32) for _ in range(L)]
+        self.fresh = [True] * L
+        self.n_tokens = 0
+
+    def wkv(self, layer, r, w, k, v, z, b):
+        from . import wkv7
+        B, T, HC = r.shape
+        ops = [i.view(B, T, HC // 64, 64) for i in (w, r, k, v, z, b)]      # the op's (w,q,k,v,z,a) order
+        S, outs, t0 = self.S[layer], [], 0
+        if self.fresh[layer] and T >= CHUNK_LEN:
+            t0 = T // CHUNK_LEN * CHUNK_LEN
+            y, s_end = wkv7.wkv7_prefill(*[i[:, :t0].contiguous() for i in ops])
+            S.copy_(s_end)
+            outs.append(y)
+        for t in range(t0, T):
+            outs.append(wkv7.wkv7_step(*[i[:, t].contiguous() for i in ops], S).unsqueeze(1))
+        self.fresh[layer] = False
+        return (outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)).view(B, T, HC)
 
 
 class RWKV(nn.Module):
@@ -253,3 +301,18 @@ class RWKV(nn.Module):
         x, num_tokens_to_pad = self.forward_features(x)
         x = self.head(x)
         return self.unpad(x, num_tokens_to_pad)
+
+    @torch.no_grad()
+    def forward_stateful(self, x, state=None, last_only=False):
+        """Inference on embedded tokens x (B,T,C) continuing from `state` (None: empty context).  No padding is
+        added: logits equal those `forward` gives for the same absolute positions of the concatenated sequence.
+        Returns (logits (B,T,V) or (B,V) with last_only, state)."""
+        if state is None:
+            state = RWKV7State(self.args, x.size(0), x.device, x.dtype)
+        v_first = torch.empty_like(x)
+        for block in self.blocks:
+            x, v_first = block(x, v_first, state)
+        state.n_tokens += x.size(1)
+        if last_only:
+            x = x[:, -1]
+        return self.head(self.ln_out(x)), state

@@ -152,3 +152,30 @@ class VisualRWKV(nn.Module):
                 break
             x = torch.cat((x, self.rwkv.emb(nxt)), dim=-2)[:, -self.args.ctx_len:, :]
         return toks, lgs, prs
+
+    @torch.no_grad()
+    def generate_stateful(self, input_ids, images, do_sample, temperature, top_p, max_new_tokens, stop_token_idx):
+        """`generate` with the recurrent state carried between tokens: one prefill over the prompt, then one
+        single-token step per new token (O(1) per token instead of re-running the whole sequence).
+        The prompt is left-padded once, like `RWKV.forward` pads it (src/model.py:301-307), so the first token
+        is the one `generate` returns; later tokens are conditioned on that same fixed prefix, whereas the
+        reference's per-step re-padding changes the number of pad tokens as the sequence grows."""
+        if do_sample:
+            raise NotImplementedError
+        from .rwkv7 import CHUNK_LEN
+        samples = {"input_ids": input_ids, "images": images, "labels": torch.full_like(input_ids, IGNORE_INDEX)}
+        x, _ = self.preparing_embedding(samples)
+        x = x[:, -self.args.ctx_len:, :]
+        rem = x.size(1) % CHUNK_LEN
+        x = self.rwkv.pad_left(x, CHUNK_LEN - rem if rem else 0)
+        logits, state = self.rwkv.forward_stateful(x, None, last_only=True)
+        toks, lgs, prs = [], [], []
+        for _ in range(max_new_tokens):
+            nxt = torch.argmax(logits, dim=-1, keepdim=True)
+            toks.append(nxt.item())
+            lgs.append(logits.gather(-1, nxt).item())
+            prs.append(torch.softmax(logits, dim=-1).gather(-1, nxt).item())
+            if toks[-1] == stop_token_idx or len(toks) == max_new_tokens:
+                break
+            logits, state = self.rwkv.forward_stateful(self.rwkv.emb(nxt), state, last_only=True)
+        return toks, lgs, prs

@@ -166,3 +166,42 @@ def RUN_CUDA_RWKV7g(q, w, k, v, a, b):
     B, T, HC = q.shape
     q, w, k, v, a, b = [i.view(B, T, HC // 64, 64) for i in [q, w, k, v, a, b]]
     return WindBackstepping.apply(w, q, k, v, a, b).view(B, T, HC)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Stateful generation.  Not in the reference, whose generate() re-runs the full forward for
+# every new token (src/model.py:513-529); same recurrence, state carried between calls.
+# ---------------------------------------------------------------------------------------------------------------
+def wkv7_prefill(w, q, k, v, z, a):
+    """(B,T,H,64) bf16, T % 16 == 0, zero initial state -> (y, S) with S (B,H,64,64) fp32 in [value row][key col]
+    order (the training op's last checkpoint, which holds S^T -- cuda/wkv7_cuda.cu:36-41 -- transposed back)."""
+    B, T, H, C = w.shape
+    assert T % CHUNK_LEN == 0 and T > 0
+    y = torch.empty_like(v)
+    s = torch.empty(B, H, T // CHUNK_LEN, C, C, dtype=torch.float32, device=w.device)
+    sa = torch.empty(B, T, H, C, dtype=torch.float32, device=w.device)
+    torch.ops.wind_backstepping.forward(w, q, k, v, z, a, y, s, sa)
+    return y, s[:, :, -1].transpose(-1, -2).contiguous()
+
+
+def wkv7_step(w, q, k, v, z, a, state):
+    """One token: (B,H,64) bf16 each, `state` (B,H,64,64) fp32 updated in place; returns y (B,H,64) bf16."""
+    B, H, C = w.shape
+    if not w.is_cuda:
+        _no_cpu()
+    if C != HEAD_SIZE:
+        raise ValueError(f"head size {C} != {HEAD_SIZE}")
+    for name, t in zip("wqkvza", (w, q, k, v, z, a)):
+        if t.dtype != torch.bfloat16 or not t.is_contiguous() or tuple(t.shape) != (B, H, C) or t.device != w.device:
+            raise ValueError(f"wkv7_step: {name} must be a contiguous bf16 ({B},{H},{C}) tensor on {w.device}")
+    if (state.dtype != torch.float32 or not state.is_contiguous() or tuple(state.shape) != (B, H, C, C)
+            or state.device != w.device):
+        raise ValueError(f"wkv7_step: state must be a contiguous fp32 ({B},{H},{C},{C}) tensor on {w.device}")
+    y = torch.empty_like(v)
+    lib = hip_lib.load()
+    with torch.cuda.device(w.device):
+        rc = lib.vrwkv_wkv7_step_bf16(B, H, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), z.data_ptr(),
+                                      a.data_ptr(), state.data_ptr(), y.data_ptr(),
+                                      torch.cuda.current_stream(w.device).cuda_stream)
+    hip_lib.check(rc, "vrwkv_wkv7_step_bf16")
+    return y
