@@ -13,7 +13,8 @@
 // buffer (c-1)&1; consumers (waves 0..3) read buffer c&1, own the two register copies of dS (S^T tiles split
 // over value columns i, S tiles split over key columns j -- no cross-wave reduction anywhere) and issue all
 // stores.  For the element-wise tail the four C-layout results are bounced through a wave-private LDS strip into
-// "one token, 4 consecutive channels per lane", the raw inputs are re-read from L2 in that layout, and the decay
+// "one token, 4 consecutive channels per lane" (with the decay-gradient integrand, formed in C layout from the
+// operand images, so that of the raw inputs only w is read a second time), and the decay
 // prefix / gradient suffix sums over the 16 tokens are in-row DPP scans (a register-only variant with quad
 // transposes and cross-row shuffles was measured 3x slower: 477 vs ~150 instructions).
 #pragma once
@@ -37,7 +38,7 @@ struct LdsB3 {
     uint16_t drT[2][N][JT];         // dR^T hi,lo  [i][t]
     uint16_t dsc[8][2][L][SS];      // dM images (producers -> consumers)
     float glast[N];
-    float res[4][L][N];             // dZt dQt dAh dKh bounced from C layout to "token per lane" for the tail
+    float res[5][L][N];             // dZt dQt dAh dKh G bounced from C layout to "token per lane" for the tail
 };
 
 struct RawB { uint2 w, q, k, z, a, v, dy; float4 sa; };
@@ -294,12 +295,10 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib) S0n[ib] = zero4();
         }
-        // raw inputs of this chunk in row layout for the tail (L2 hits: the producers read them two chunks ago)
+        // raw decay of this chunk in row layout for the tail (the only input read twice; the producers read it two
+        // chunks ago).  q,k,z,a are NOT re-read: their products with the gradients are formed in C layout from the
+        // hi/lo operand images already in registers (dq q = dQt Qt, da a = dAh Ah, dk k = dKh Kh, dz z = dZt Zt).
         const uint2 tw = *reinterpret_cast<const uint2*>(p.w + cbase + row_off);
-        const uint2 tq = *reinterpret_cast<const uint2*>(p.q + cbase + row_off);
-        const uint2 tk = *reinterpret_cast<const uint2*>(p.k + cbase + row_off);
-        const uint2 tz = *reinterpret_cast<const uint2*>(p.z + cbase + row_off);
-        const uint2 ta = *reinterpret_cast<const uint2*>(p.a + cbase + row_off);
         const uint2 zth = ld8(&B.trn[0][j][4 * g]), ztl = ld8(&B.trn[1][j][4 * g]);
         const uint2 qth = ld8(&B.trn[2][j][4 * g]), qtl = ld8(&B.trn[3][j][4 * g]);
         f32x4 dZt, dQt, dAh, dKh;
@@ -350,6 +349,19 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
             dAh = mm_small(dAh, lds.dsc[5][0], lds.dsc[5][1], c16, g, qth, qtl);                    // dM_qa^T Qt
             dKh = mm_small(dKh, lds.dsc[3][0], lds.dsc[3][1], c16, g, zth, ztl);                    // dM_zk^T Zt
             dKh = mm_small(dKh, lds.dsc[7][0], lds.dsc[7][1], c16, g, qth, qtl);                    // dM_qk^T Qt
+            // decay-gradient integrand G[t][j] = dq q - da a - dk k + (dz z)[t+1]   (t = 4g + r, C layout)
+            float zh[4], zl[4], qh[4], ql[4], ah[4], al[4], kh[4], kl[4], pz[4];
+            unpack4(zth, zh); unpack4(ztl, zl); unpack4(qth, qh); unpack4(qtl, ql);
+            unpack4(ahh, ah); unpack4(ahl, al); unpack4(khh, kh); unpack4(khl, kl);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pz[r] = dZt[r] * (zh[r] + zl[r]);
+            float pzn = lane_bcast(pz[0], (lane + 16) & 63);          // token 4(g+1) of the same column
+            pzn = g == 3 ? 0.f : pzn;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float nx = r < 3 ? pz[r < 3 ? r + 1 : 3] : pzn;
+                lds.res[4][4 * g + r][j] = dQt[r] * (qh[r] + ql[r]) - dAh[r] * (ah[r] + al[r]) - dKh[r] * (kh[r] + kl[r]) + nx;
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -364,12 +376,13 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
             const float4 rq = *reinterpret_cast<const float4*>(&lds.res[1][c16][c0]);
             const float4 ra = *reinterpret_cast<const float4*>(&lds.res[2][c16][c0]);
             const float4 rk = *reinterpret_cast<const float4*>(&lds.res[3][c16][c0]);
+            const float4 rg = *reinterpret_cast<const float4*>(&lds.res[4][c16][c0]);
             const float4 gl4 = *reinterpret_cast<const float4*>(&lds.glast[c0]);
             const float dzt[4] = {rz.x, rz.y, rz.z, rz.w}, dqt[4] = {rq.x, rq.y, rq.z, rq.w};
             const float dah[4] = {ra.x, ra.y, ra.z, ra.w}, dkh[4] = {rk.x, rk.y, rk.z, rk.w};
-            const float glv[4] = {gl4.x, gl4.y, gl4.z, gl4.w};
-            float wr[4], q[4], k[4], z[4], a[4];
-            unpack4(tw, wr); unpack4(tq, q); unpack4(tk, k); unpack4(tz, z); unpack4(ta, a);
+            const float glv[4] = {gl4.x, gl4.y, gl4.z, gl4.w}, gin[4] = {rg.x, rg.y, rg.z, rg.w};
+            float wr[4];
+            unpack4(tw, wr);
             float dz[4], dq[4], da[4], dk[4], dw[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -378,7 +391,7 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
                 x += dpp_shr<1>(x); x += dpp_shr<2>(x); x += dpp_shr<4>(x); x += dpp_shr<8>(x);
                 const float cc = fast_exp(x), cp = fast_exp(x - lw), ic = fast_exp(-x);
                 dz[e] = dzt[e] * cp; dq[e] = dqt[e] * cc; da[e] = dah[e] * ic; dk[e] = dkh[e] * ic;
-                float gt = dq[e] * q[e] - da[e] * a[e] - dk[e] * k[e] + dpp_shl<1>(dz[e] * z[e]);
+                float gt = gin[e];
                 if (c16 == 15) gt += glv[e];
                 gt += dpp_shl<1>(gt); gt += dpp_shl<2>(gt); gt += dpp_shl<4>(gt); gt += dpp_shl<8>(gt);   // suffix sum over t
                 dw[e] = gt * lw;
