@@ -23,6 +23,8 @@
 
 namespace wkv7c {
 
+constexpr int RS = 68;              // row stride (floats) of the tail bounce strips: C-layout writes (rows 4g+r) and
+                                    // token-per-lane float4 reads (rows c16) are both bank-conflict free
 struct BufB {                       // produced per chunk, double buffered
     uint16_t ab[4][L][TJ];          // Ab_hi Ab_lo Kb_hi Kb_lo            [t][j]
     uint16_t trn[8][N][JT];         // ZtT QtT AhT KhT (hi,lo)            [j][t]
@@ -38,8 +40,15 @@ struct LdsB3 {
     uint16_t drT[2][N][JT];         // dR^T hi,lo  [i][t]
     uint16_t dsc[8][2][L][SS];      // dM images (producers -> consumers)
     float glast[N];
-    float res[5][L][N];             // dZt dQt dAh dKh G bounced from C layout to "token per lane" for the tail
+    float res[3][L][RS];            // dAh dKh G bounced from C layout to "token per lane" for the tail; dZt and dQt
+                                    // use the dr/drT area, which is dead in segment 3 (res_mat below)
 };
+static_assert(sizeof(uint16_t) * (2 * L * TJ + 2 * N * JT) >= sizeof(float) * 2 * L * RS, "dZt,dQt bounce must fit in dr+drT");
+static_assert(__builtin_offsetof(LdsB3, dr) % 16 == 0 && __builtin_offsetof(LdsB3, res) % 16 == 0, "float4 reads of the bounce strips");
+static_assert(__builtin_offsetof(LdsB3, drT) == __builtin_offsetof(LdsB3, dr) + sizeof(uint16_t) * 2 * L * TJ, "dr and drT contiguous");
+DEVFN float* res_mat(LdsB3& lds, int m) {       // m: 0 dZt, 1 dQt, 2 dAh, 3 dKh, 4 G ; row stride RS floats
+    return m < 2 ? reinterpret_cast<float*>(&lds.dr[0][0][0]) + m * L * RS : &lds.res[m - 2][0][0];
+}
 
 struct RawB { uint2 w, q, k, z, a, v, dy; float4 sa; };
 
@@ -360,23 +369,23 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float nx = r < 3 ? pz[r < 3 ? r + 1 : 3] : pzn;
-                lds.res[4][4 * g + r][j] = dQt[r] * (qh[r] + ql[r]) - dAh[r] * (ah[r] + al[r]) - dKh[r] * (kh[r] + kl[r]) + nx;
+                res_mat(lds, 4)[(4 * g + r) * RS + j] = dQt[r] * (qh[r] + ql[r]) - dAh[r] * (ah[r] + al[r]) - dKh[r] * (kh[r] + kl[r]) + nx;
             }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            lds.res[0][4 * g + r][j] = dZt[r];
-            lds.res[1][4 * g + r][j] = dQt[r];
-            lds.res[2][4 * g + r][j] = dAh[r];
-            lds.res[3][4 * g + r][j] = dKh[r];
+            res_mat(lds, 0)[(4 * g + r) * RS + j] = dZt[r];
+            res_mat(lds, 1)[(4 * g + r) * RS + j] = dQt[r];
+            res_mat(lds, 2)[(4 * g + r) * RS + j] = dAh[r];
+            res_mat(lds, 3)[(4 * g + r) * RS + j] = dKh[r];
         }
         wave_lds_fence();           // res columns [16w,16w+16) and glast are written and read by this wave only
         {
-            const float4 rz = *reinterpret_cast<const float4*>(&lds.res[0][c16][c0]);
-            const float4 rq = *reinterpret_cast<const float4*>(&lds.res[1][c16][c0]);
-            const float4 ra = *reinterpret_cast<const float4*>(&lds.res[2][c16][c0]);
-            const float4 rk = *reinterpret_cast<const float4*>(&lds.res[3][c16][c0]);
-            const float4 rg = *reinterpret_cast<const float4*>(&lds.res[4][c16][c0]);
+            const float4 rz = *reinterpret_cast<const float4*>(res_mat(lds, 0) + c16 * RS + c0);
+            const float4 rq = *reinterpret_cast<const float4*>(res_mat(lds, 1) + c16 * RS + c0);
+            const float4 ra = *reinterpret_cast<const float4*>(res_mat(lds, 2) + c16 * RS + c0);
+            const float4 rk = *reinterpret_cast<const float4*>(res_mat(lds, 3) + c16 * RS + c0);
+            const float4 rg = *reinterpret_cast<const float4*>(res_mat(lds, 4) + c16 * RS + c0);
             const float4 gl4 = *reinterpret_cast<const float4*>(&lds.glast[c0]);
             const float dzt[4] = {rz.x, rz.y, rz.z, rz.w}, dqt[4] = {rq.x, rq.y, rq.z, rq.w};
             const float dah[4] = {ra.x, ra.y, ra.z, ra.w}, dkh[4] = {rk.x, rk.y, rk.z, rk.w};
