@@ -155,6 +155,26 @@ DEVFN f32x4 mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
     emu::wave_barrier();
     return d;
 }
+DEVFN f32x4 mfma_16x16x16_bf16(bf16x4 a, bf16x4 b, f32x4 c) {
+    int me = emu::flat_tid(), wb = emu::wave_base(), l = me & 63;
+    short* s = (short*)emu::slot(me);
+    for (int e = 0; e < 4; ++e) { s[e] = a[e]; s[4 + e] = b[e]; }
+    emu::wave_barrier();
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) * 4 + r, col = l & 15;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            short av = ((short*)emu::slot(wb + (k >> 2) * 16 + row))[k & 3];
+            short bv = ((short*)emu::slot(wb + (k >> 2) * 16 + col))[4 + (k & 3)];
+            acc += bf16_to_f32((uint16_t)av) * bf16_to_f32((uint16_t)bv);
+        }
+        d[r] = acc;
+    }
+    emu::wave_barrier();
+    return d;
+}
+DEVFN bf16x4 mk4(uint2 u) { bf16x4 r; __builtin_memcpy(&r, &u, 8); return r; }
 DEVFN f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     int me = emu::flat_tid(), wb = emu::wave_base(), l = me & 63;
     short* s = (short*)emu::slot(me);

@@ -15,7 +15,8 @@ def _probe(lib, which, a, b, dshape):
     return d
 
 
-@pytest.mark.parametrize("which,M,N,K,bf", [(0, 16, 16, 4, False), (1, 32, 32, 2, False), (2, 16, 16, 32, True), (3, 32, 32, 16, True)])
+@pytest.mark.parametrize("which,M,N,K,bf", [(0, 16, 16, 4, False), (1, 32, 32, 2, False), (2, 16, 16, 32, True), (3, 32, 32, 16, True),
+                                              (5, 16, 16, 16, True)])
 def test_mfma_maps(hip_lib, which, M, N, K, bf):
     g = torch.Generator().manual_seed(which)
     a = torch.randn(M, K, generator=g)
@@ -43,3 +44,15 @@ def test_lane_primitives(hip_lib):
     assert torch.equal(d[9], x[(lanes & ~3) | torch.tensor([1, 2, 3, 3])[q]])             # quad_perm [1,2,3,3]
     for k in range(4):   # quad_transpose: out[k] of lane m = in[m] of lane k of the quad
         assert torch.equal(d[10 + k], x[(lanes & ~3) | k] + 100.0 * q)
+
+
+def test_mfma_issue_rate_report(hip_lib):
+    """Not a pass/fail property: prints cycles per MFMA (1/4/8 independent chains) for the K=32 and K=16 bf16 forms."""
+    d = torch.zeros(8, device="cuda")
+    rc = hip_lib.vrwkv_debug_probe(6, d.data_ptr(), 0, d.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    r = d.cpu().tolist()
+    print("MFMA_RATE cycles/instr: x32 chains1 %.1f chains4 %.1f chains8 %.1f | x16 chains1 %.1f chains4 %.1f chains8 %.1f"
+          % (r[0], r[1], r[5], r[2], r[3], r[4]))
+    assert all(x > 0 for x in r[:6])

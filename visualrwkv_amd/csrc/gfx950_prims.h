@@ -133,6 +133,10 @@ DEVFN f32x4 mfma_16x16x4_f32(float a, float b, f32x4 c) { return __builtin_amdgc
 DEVFN f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 // 16x16x32 bf16: A[i=l&15][k=(l>>4)*8+e], B[k=(l>>4)*8+e][j=l&15], e=0..7; C/D as 16x16x4.
 DEVFN f32x4 mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// 16x16x16 bf16 (the CDNA3 form, still present): A[i=l&15][k=(l>>4)*4+e], B[k=(l>>4)*4+e][j=l&15], e=0..3 -- the k index
+// of a lane is exactly the row index of its C/D registers, so an accumulator tile is a B operand as it stands.
+DEVFN f32x4 mfma_16x16x16_bf16(bf16x4 a, bf16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+DEVFN bf16x4 mk4(uint2 u) { return __builtin_bit_cast(bf16x4, u); }
 // 32x32x16 bf16: A[i=l&31][k=(l>>5)*8+e], B[k=(l>>5)*8+e][j=l&31]; C/D as 32x32x2.
 DEVFN f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 

@@ -63,6 +63,47 @@ __global__ void probe_lanes(const float* in, float* out) {
     { f32x4 v = {x, x + 100.f, x + 200.f, x + 300.f}; v = quad_transpose(v); out[640 + l] = v[0]; out[704 + l] = v[1]; out[768 + l] = v[2]; out[832 + l] = v[3]; }
 }
 
+// D[16][16] = A[16][16] * B[16][16] with the K=16 bf16 MFMA
+__global__ void probe_16x16x16_bf16(const float* A, const float* B, float* D) {
+    const int l = threadIdx.x;
+    bf16x4 a, b;
+    for (int e = 0; e < 4; ++e) {
+        const int k = (l >> 4) * 4 + e;
+        a[e] = (short)f32_to_bf16_bits(A[(l & 15) * 16 + k]);
+        b[e] = (short)f32_to_bf16_bits(B[k * 16 + (l & 15)]);
+    }
+    f32x4 d = mfma_16x16x16_bf16(a, b, f32x4{0.f, 0.f, 0.f, 0.f});
+    for (int r = 0; r < 4; ++r) D[((l >> 4) * 4 + r) * 16 + (l & 15)] = d[r];
+}
+
+// Issue rate of the bf16 MFMAs on one SIMD: NCH independent accumulator chains, 512 rounds; cycles per MFMA -> D[0..5]
+template <int K, int NCH>
+DEVFN float mfma_rate(int l) {
+    f32x4 acc[NCH];
+    for (int c = 0; c < NCH; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 a8; bf16x4 a4;
+    for (int e = 0; e < 8; ++e) a8[e] = (short)(0x3f80 + l + e);
+    for (int e = 0; e < 4; ++e) a4[e] = (short)(0x3f80 + l + e);
+    const long t0 = clock64_();
+    for (int it = 0; it < 512; ++it) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (K == 32) acc[c] = mfma_16x16x32_bf16(a8, a8, acc[c]);
+            else acc[c] = mfma_16x16x16_bf16(a4, a4, acc[c]);
+        }
+    }
+    float sink = 0.f;
+    for (int c = 0; c < NCH; ++c) sink += acc[c][0];
+    const long t1 = clock64_();
+    return (float)(t1 - t0) / (512.f * NCH) + (sink == 12345.f ? 1.f : 0.f);
+}
+__global__ void probe_mfma_rate(float* D) {
+    const int l = threadIdx.x;
+    const float r0 = mfma_rate<32, 1>(l), r1 = mfma_rate<32, 4>(l), r2 = mfma_rate<16, 1>(l), r3 = mfma_rate<16, 4>(l);
+    const float r4 = mfma_rate<16, 8>(l), r5 = mfma_rate<32, 8>(l);
+    if (l == 0) { D[0] = r0; D[1] = r1; D[2] = r2; D[3] = r3; D[4] = r4; D[5] = r5; }
+}
+
 }  // namespace
 
 extern "C" int vrwkv_debug_probe(int which, const float* a, const float* b, float* d, void* stream) {
@@ -74,6 +115,8 @@ extern "C" int vrwkv_debug_probe(int which, const float* a, const float* b, floa
         case 2: hipLaunchKernelGGL(probe_16x16x32_bf16, dim3(1), dim3(64), 0, st, a, b, d); break;
         case 3: hipLaunchKernelGGL(probe_32x32x16_bf16, dim3(1), dim3(64), 0, st, a, b, d); break;
         case 4: hipLaunchKernelGGL(probe_lanes, dim3(1), dim3(64), 0, st, a, d); break;
+        case 5: hipLaunchKernelGGL(probe_16x16x16_bf16, dim3(1), dim3(64), 0, st, a, b, d); break;
+        case 6: hipLaunchKernelGGL(probe_mfma_rate, dim3(1), dim3(64), 0, st, d); break;
         default: return VRWKV_EINVAL;
     }
     hipError_t e = hipGetLastError();

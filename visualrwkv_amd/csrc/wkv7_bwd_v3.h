@@ -272,8 +272,9 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
             st8(&lds.drT[0][16 * wave + c16][4 * g], rh);
             st8(&lds.drT[1][16 * wave + c16][4 * g], rl);
             uint16_t* dvp = p.dv + cbase;
+            const uint32_t v01 = cvt_pk_bf16(dV[0], dV[1]), v23 = cvt_pk_bf16(dV[2], dV[3]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dvp[dv_off + r * ts] = (uint16_t)f32_to_bf16_bits(dV[r]);
+            for (int r = 0; r < 4; ++r) dvp[dv_off + r * ts] = (uint16_t)((r < 2 ? v01 : v23) >> (16 * (r & 1)));
             // dS^T <- diag(c_L) dS^T + [Qt^T | Zt^T] [dY ; dR]
             const bf16x8 b1 = mk8(dy, rh), b2 = mk8(0u, 0u, rl.x, rl.y);
 #pragma unroll

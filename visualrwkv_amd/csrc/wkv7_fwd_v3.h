@@ -256,10 +256,11 @@ __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
                 *reinterpret_cast<float4*>(sa_c + out_off) = make_float4(sat[0], sat[1], sat[2], sat[3]);
                 *reinterpret_cast<uint2*>(y_c + out_off) = make_uint2(cvt_pk_bf16(yt[0], yt[1]), cvt_pk_bf16(yt[2], yt[3]));
             } else {
+                const uint32_t y01 = cvt_pk_bf16(Y[0], Y[1]), y23 = cvt_pk_bf16(Y[2], Y[3]);   // one v_cvt_pk per pair
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     sa_c[out_off + r * ts] = SA[r];
-                    y_c[out_off + r * ts] = (uint16_t)f32_to_bf16_bits(Y[r]);
+                    y_c[out_off + r * ts] = (uint16_t)((r < 2 ? y01 : y23) >> (16 * (r & 1)));
                 }
             }
         }
