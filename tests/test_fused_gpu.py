@@ -32,7 +32,8 @@ def _check(mine, ref, tol=TOL, names=None):
         assert e < tol, (names[i] if names else i, e)
 
 
-@pytest.mark.parametrize("B,T,C,M", [(2, 5, 128, 6), (3, 33, 768, 6), (1, 40, 2048, 1)])
+@pytest.mark.parametrize("B,T,C,M", [(2, 5, 128, 6), (3, 33, 768, 6), (1, 40, 2048, 1), (3, 1, 64, 6), (7, 592, 256, 6),
+                                     (2, 2624, 2048, 6), (1, 17, 4608, 1)])
 def test_mix(B, T, C, M):
     from visualrwkv_amd import fused
     x = _rnd(B, T, C, seed=1)

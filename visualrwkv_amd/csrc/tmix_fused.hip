@@ -61,6 +61,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(int G, long width, const fl
         *reinterpret_cast<float4*>(out + col) = t;
     }
 }
+// Backward kernels: workgroup g of G owns the contiguous token range [ntok g / G, ntok (g+1) / G) -- balanced to one
+// token (a 16-token tile grid left 2 or 3 tiles per workgroup at the benchmark shape: 15 % idle).
+DEVFN long range_lo(long ntok) { return ntok * blockIdx.x / gridDim.x; }
+DEVFN long range_hi(long ntok) { return ntok * (blockIdx.x + 1) / gridDim.x; }
 DEVFN float sigmoidf_(float x) { return 1.f / (1.f + fast_exp(-x)); }
 
 struct Ptrs6 { const uint16_t* p[MAXM]; };
@@ -95,43 +99,82 @@ __global__ void mix_fwd_kernel(long ntok, int T, int C, const uint16_t* __restri
     }
 }
 
-// dx[n] = sum_m d_m[n] (1 - mu_m) + [t < T-1] sum_m d_m[n+1] mu_m ;  dmu_m += d_m[n] * (x[n-1] - x[n]).
-// Every token is independent (row n+1 is re-read, it is an L2/L1 hit); a variant that carried row n in registers
-// to read each row once measured 1.7x SLOWER -- the loop-carried state removes the memory-level parallelism.
+// dx[n] = A[n] + [t < T-1] Bv[n+1],  A[n] = sum_m d_m[n] (1 - mu_m) = Dsum[n] - Bv[n],  Bv[n] = sum_m d_m[n] mu_m ;
+// dmu_m += d_m[n] * (x[n-1] - x[n]).
+// A workgroup owns one contiguous token range (balanced to +-1 token over the grid); a thread owns 4 channels and
+// walks the range once: every row of x and of the M gradients is read exactly once (plus one boundary row per
+// range), and the only loop-carried values are A[n-1] and x[n-1] (8 registers) -- the loads of later rows do not
+// depend on them, so the unrolled loop keeps many rows in flight.  (Reading row n+1 again for every token, as the
+// first version did, doubled the L2->CU traffic and needed 200+ VGPRs: 1.9 ms per call instead of ~0.4 ms.)
+struct V4 { float f[4]; };
+DEVFN V4 ld4f(const uint16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    V4 r;
+    r.f[0] = bf16_lo(u.x); r.f[1] = bf16_hi(u.x); r.f[2] = bf16_lo(u.y); r.f[3] = bf16_hi(u.y);
+    return r;
+}
+DEVFN void st4f(uint16_t* p, const V4& v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(cvt_pk_bf16(v.f[0], v.f[1]), cvt_pk_bf16(v.f[2], v.f[3]));
+}
 template <int M>
-__global__ void mix_bwd_kernel(long ntok, int T, int C, const uint16_t* __restrict__ x, Ptrs6 mu, Ptrs6 dout,
-                               uint16_t* __restrict__ dx, float* __restrict__ dmu) {
-    const int c0 = threadIdx.x * 8;
-    V8 m[M], gm[M];
+__global__ __launch_bounds__(512) void mix_bwd_kernel(long ntok, int T, int C, const uint16_t* __restrict__ x, Ptrs6 mu, Ptrs6 dout,
+                                                      uint16_t* __restrict__ dx, float* __restrict__ dmu) {
+    const long lo = ntok * blockIdx.x / gridDim.x, hi = ntok * (blockIdx.x + 1) / gridDim.x;
+    for (int c0 = threadIdx.x * 4; c0 < C; c0 += blockDim.x * 4) {
+        V4 m[M], gm[M];
 #pragma unroll
-    for (int i = 0; i < M; ++i) { m[i] = ld8f(mu.p[i] + c0); gm[i] = zero8(); }
-    for (long nb = (long)blockIdx.x * TPB; nb < ntok; nb += (long)gridDim.x * TPB) {
-        const long ne = nb + TPB < ntok ? nb + TPB : ntok;
-#pragma unroll 2
-        for (long n = nb; n < ne; ++n) {
-            const int t = (int)(n % T);
-            const V8 xv = ld8f(x + n * C + c0);
-            const V8 xp = ld8f(x + (t != 0 ? n - 1 : n) * C + c0);
-            const bool has_next = t != T - 1;
-            const long nn = has_next ? n + 1 : n;
-            V8 acc = zero8();
+        for (int i = 0; i < M; ++i) {
+            m[i] = ld4f(mu.p[i] + c0);
 #pragma unroll
-            for (int j = 0; j < M; ++j) {
-                const V8 d = ld8f(dout.p[j] + n * C + c0);
-                const V8 dn = ld8f(dout.p[j] + nn * C + c0);
+            for (int e = 0; e < 4; ++e) gm[i].f[e] = 0.f;
+        }
+        V4 xprev, aprev;
+        {
+            const V4 t = ld4f(x + (lo > 0 ? lo - 1 : 0) * C + c0);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float xx = (t != 0 ? xp.f[e] : 0.f) - xv.f[e];
-                    acc.f[e] = fmaf(d.f[e], 1.f - m[j].f[e], acc.f[e]);
-                    acc.f[e] = fmaf(has_next ? dn.f[e] : 0.f, m[j].f[e], acc.f[e]);
-                    gm[j].f[e] = fmaf(d.f[e], xx, gm[j].f[e]);
+            for (int e = 0; e < 4; ++e) { xprev.f[e] = t.f[e]; aprev.f[e] = 0.f; }
+        }
+        // rows lo .. hi-1 in full; row hi (if it continues the last sequence) contributes only Bv to dx[hi-1]
+        const long last = (hi < ntok && hi % T != 0) ? hi : hi - 1;
+#pragma unroll 4
+        for (long n = lo; n <= last; ++n) {
+            const bool inside = n < hi;
+            const bool cont = n % T != 0;                   // row n-1 belongs to the same sequence
+            V4 d[M];
+#pragma unroll
+            for (int j = 0; j < M; ++j) d[j] = ld4f(dout.p[j] + n * C + c0);
+            const V4 xv = ld4f(x + (inside ? n : n - 1) * C + c0);
+            V4 dsum, bv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { dsum.f[e] = 0.f; bv.f[e] = 0.f; }
+#pragma unroll
+            for (int j = 0; j < M; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { dsum.f[e] += d[j].f[e]; bv.f[e] = fmaf(d[j].f[e], m[j].f[e], bv.f[e]); }
+            if (n > lo) {
+                V4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.f[e] = aprev.f[e] + (cont ? bv.f[e] : 0.f);
+                st4f(dx + (n - 1) * C + c0, o);
+            }
+            if (inside) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xx = (cont ? xprev.f[e] : 0.f) - xv.f[e];
+#pragma unroll
+                    for (int j = 0; j < M; ++j) gm[j].f[e] = fmaf(d[j].f[e], xx, gm[j].f[e]);
+                    aprev.f[e] = dsum.f[e] - bv.f[e];
+                    xprev.f[e] = xv.f[e];
                 }
             }
-            st8f(dx + n * C + c0, acc);
+        }
+        if (last == hi - 1 && hi > lo) st4f(dx + (hi - 1) * C + c0, aprev);      // no successor row: dx = A
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            float* dst = dmu + ((size_t)blockIdx.x * M + j) * C + c0;
+            *reinterpret_cast<float4*>(dst) = make_float4(gm[j].f[0], gm[j].f[1], gm[j].f[2], gm[j].f[3]);
         }
     }
-#pragma unroll
-    for (int j = 0; j < M; ++j) put_partial(dmu, M, j, C, c0, gm[j]);
 }
 
 // ---------------------------------------------------------------------------------------------- F2: decay soft-clamp
@@ -158,8 +201,7 @@ __global__ void decay_bwd_kernel(long ntok, int C, const uint16_t* __restrict__ 
     const int c0 = threadIdx.x * 8;
     const V8 b = ld8f(w0 + c0);
     V8 g0 = zero8();
-    for (long nb = (long)blockIdx.x * TPB; nb < ntok; nb += (long)gridDim.x * TPB)
-    for (long n = nb; n < nb + TPB && n < ntok; ++n) {
+    for (long n = range_lo(ntok), hi = range_hi(ntok); n < hi; ++n) {
         const V8 hv = ld8f(h + n * C + c0), d = ld8f(dw + n * C + c0);
         V8 o;
 #pragma unroll
@@ -224,8 +266,7 @@ __global__ void kva_bwd_kernel(KvaBwd p) {
     V8 v0 = zero8();
     if (p.has_vres) v0 = ld8f(p.v0 + c0);
     V8 g_kk = zero8(), g_ka = zero8(), g_a0 = zero8(), g_v0 = zero8();
-    for (long nb = (long)blockIdx.x * TPB; nb < p.ntok; nb += (long)gridDim.x * TPB)
-    for (long n = nb; n < nb + TPB && n < p.ntok; ++n) {
+    for (long n = range_lo(p.ntok), hi = range_hi(p.ntok); n < hi; ++n) {
         const long o = n * C + c0;
         const V8 k = ld8f(p.k + o), al = ld8f(p.al + o);
         const V8 dk2 = ld8f(p.dk2 + o), dz = ld8f(p.dz + o), db = ld8f(p.db + o);
@@ -319,8 +360,7 @@ __global__ void post_bwd_kernel(PostBwd p) {
     const int c0 = threadIdx.x * 8, C = p.C;
     const V8 lw = ld8f(p.ln_w + c0), lb = ld8f(p.ln_b + c0), rk = ld8f(p.r_k + c0);
     V8 g_w = zero8(), g_b = zero8(), g_rk = zero8();
-    for (long nb = (long)blockIdx.x * TPB; nb < p.ntok; nb += (long)gridDim.x * TPB)
-    for (long n = nb; n < nb + TPB && n < p.ntok; ++n) {
+    for (long n = range_lo(p.ntok), hi = range_hi(p.ntok); n < hi; ++n) {
         const long o = n * C + c0;
         const V8 y = ld8f(p.y + o), r = ld8f(p.r + o), k = ld8f(p.k + o), v = ld8f(p.v + o), g = ld8f(p.g + o);
         const V8 d = ld8f(p.dout + o);
@@ -418,8 +458,9 @@ int vrwkv_mix_bwd_bf16(long ntok, int T, int C, int M, const void* x, const void
     for (int i = 0; i < M; ++i) { m.p[i] = (const uint16_t*)mu[i]; d.p[i] = (const uint16_t*)dout[i]; if (!m.p[i] || !d.p[i]) return VRWKV_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     const int G = bwd_grid(ntok);
-    if (M == 6) hipLaunchKernelGGL(mix_bwd_kernel<6>, dim3(G), dim3(C / 8), 0, st, ntok, T, C, (const uint16_t*)x, m, d, (uint16_t*)dx, ws);
-    else hipLaunchKernelGGL(mix_bwd_kernel<1>, dim3(G), dim3(C / 8), 0, st, ntok, T, C, (const uint16_t*)x, m, d, (uint16_t*)dx, ws);
+    const int threads = C / 4 < 512 ? C / 4 : 512;
+    if (M == 6) hipLaunchKernelGGL(mix_bwd_kernel<6>, dim3(G), dim3(threads), 0, st, ntok, T, C, (const uint16_t*)x, m, d, (uint16_t*)dx, ws);
+    else hipLaunchKernelGGL(mix_bwd_kernel<1>, dim3(G), dim3(threads), 0, st, ntok, T, C, (const uint16_t*)x, m, d, (uint16_t*)dx, ws);
     colsum(G, (long)M * C, ws, dmu, st);
     return done();
 }
