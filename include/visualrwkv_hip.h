@@ -50,6 +50,19 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H,
                              void* dw, void* dq, void* dk, void* dv, void* dz, void* da,
                              void* stream);
 
+/* Residual add + LayerNorm in one pass (Block.forward: x = x + att(ln1(x)); x = x + ffn(ln2(x)), and ln_out --
+ * VisualRWKV-v7/v7.00/src/model.py:247-254,318; the reference runs a bf16 add followed by nn.LayerNorm).
+ *   fwd: xn = bf16(x + delta) (delta may be NULL: no add, xn not written), y = LayerNorm(xn; w, b, eps); mean/rstd
+ *        (ntok fp32 each) are kept for the backward.
+ *   bwd: dx = dres (may be NULL) + LayerNorm-backward(dy); dwb = [dw | db] (2*C fp32, overwritten);
+ *        ws: vrwkv_add_ln_ws_floats(ntok, C) floats of scratch.
+ * x, delta, xn, y, dy, dres, dx: (ntok, C) bf16; w, b: (C) bf16; C % 64 == 0, C <= 8192. */
+long vrwkv_add_ln_ws_floats(long ntok, int C);
+int vrwkv_add_ln_fwd_bf16(long ntok, int C, float eps, const void* x, const void* delta, const void* w, const void* b,
+                          void* xn, void* y, float* mean, float* rstd, void* stream);
+int vrwkv_add_ln_bwd_bf16(long ntok, int C, const void* dy, const void* dres, const void* xn, const float* mean,
+                          const float* rstd, const void* w, void* dx, float* dwb, float* ws, void* stream);
+
 /* WKV7 single-token step with carried state (stateful generation; the reference re-runs the whole forward per new
  * token, VisualRWKV-v7/v7.00/src/model.py:513-529).  w..a, y: (B,H,64) bf16; state: (B,H,64,64) f32, S[i][j] with
  * i = value row, j = key column, updated in place.  (The training op's checkpoint `s` holds S^T.) */

@@ -141,6 +141,52 @@ def test_relu_sq():
     _check([y, hh.grad], [ry, rdh])
 
 
+@pytest.mark.parametrize("ntok,C,has_delta", [(7, 64, True), (33, 512, True), (100, 768, False), (64, 2048, True),
+                                              (5, 8192, True), (2624, 2048, True), (3000, 1024, False)])
+def test_add_ln(ntok, C, has_delta):
+    """Residual add + LayerNorm (csrc/ln_fused.hip) vs the reference sequence: bf16 add, then nn.LayerNorm."""
+    from visualrwkv_amd import fused
+    x = _rnd(ntok, C, seed=1, scale=2.0) + 0.5
+    delta = _rnd(ntok, C, seed=2) if has_delta else None
+    ln = torch.nn.LayerNorm(C).cuda().bfloat16()
+    with torch.no_grad():
+        ln.weight.copy_(_rnd(C, seed=3) * 0.5 + 1)
+        ln.bias.copy_(_rnd(C, seed=4) * 0.1)
+    g_xn, g_y = _rnd(ntok, C, seed=5), _rnd(ntok, C, seed=6)
+
+    def ref(x, w, b, *d):
+        xn = (x + d[0]).bfloat16().float() if d else x
+        return xn, F.layer_norm(xn, (C,), w, b, ln.eps)
+
+    ins = [x, ln.weight.detach(), ln.bias.detach()] + ([delta] if has_delta else [])
+    xs = [x.clone().requires_grad_(True)] + ([delta.clone().requires_grad_(True)] if has_delta else [])
+    ln.zero_grad()
+    xn, y = fused.add_ln(xs[0], xs[1] if has_delta else None, ln)
+    if has_delta:
+        torch.autograd.backward([xn, y], [g_xn, g_y])
+    else:
+        torch.autograd.backward([y], [g_y])
+
+    # fp32 reference with a straight-through rounding of the residual sum
+    rx = [t.detach().float().requires_grad_(True) for t in ins]
+    if has_delta:
+        s = rx[0] + rx[3]
+        r_xn = s + (s.bfloat16().float() - s).detach()
+    else:
+        r_xn = rx[0]
+    r_y = F.layer_norm(r_xn, (C,), rx[1], rx[2], ln.eps)
+    if has_delta:
+        torch.autograd.backward([r_xn, r_y], [g_xn.float(), g_y.float()])
+    else:
+        torch.autograd.backward([r_y], [g_y.float()])
+    if has_delta:
+        assert torch.equal(xn, (x.float() + delta.float()).bfloat16())         # the add is exactly the bf16 add
+        _check([xs[1].grad], [rx[3].grad])
+    _check([y], [r_y])
+    _check([xs[0].grad], [rx[0].grad])
+    _check([ln.weight.grad, ln.bias.grad], [rx[1].grad, rx[2].grad], tol=2e-3)
+
+
 def test_fused_rejects_wrong_inputs():
     from visualrwkv_amd import fused
     x = torch.randn(1, 4, 128, device="cuda")          # fp32: must raise, not fall back

@@ -226,6 +226,79 @@ post = _Post.apply
 relu_sq = _ReluSq.apply
 
 
+class _AddLN(torch.autograd.Function):
+    """(xn, y) = (x + delta, LayerNorm(x + delta));  with delta None: y = LayerNorm(x) only (csrc/ln_fused.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, delta, w, b, eps):
+        C = x.shape[-1]
+        x = x.contiguous()
+        delta = delta.contiguous() if delta is not None else None
+        wc, bc = w.contiguous(), b.contiguous()
+        _chk(x, delta, wc, bc)
+        if delta is not None and delta.shape != x.shape:
+            raise ValueError("add_ln: x and delta must have the same shape")
+        ntok = x.numel() // C
+        xn = torch.empty_like(x) if delta is not None else x
+        y = torch.empty_like(x)
+        mean = torch.empty(ntok, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(ntok, dtype=torch.float32, device=x.device)
+        rc = hip_lib.load().vrwkv_add_ln_fwd_bf16(ntok, C, float(eps), x.data_ptr(), _p(delta), wc.data_ptr(), bc.data_ptr(),
+                                                  xn.data_ptr() if delta is not None else 0, y.data_ptr(),
+                                                  mean.data_ptr(), rstd.data_ptr(), _stream(x))
+        hip_lib.check(rc, "vrwkv_add_ln_fwd_bf16")
+        ctx.save_for_backward(xn, mean, rstd, wc)
+        ctx.has_delta = delta is not None
+        if delta is None:
+            return y
+        return xn, y
+
+    @staticmethod
+    def backward(ctx, *grads):
+        xn, mean, rstd, wc = ctx.saved_tensors
+        d_xn, dy = grads if ctx.has_delta else (None, grads[0])
+        C = xn.shape[-1]
+        ntok = xn.numel() // C
+        dy = dy.contiguous()
+        d_xn = d_xn.contiguous() if d_xn is not None else None
+        _chk(dy, d_xn)
+        dx = torch.empty_like(xn)
+        dwb = torch.empty(2, C, dtype=torch.float32, device=xn.device)
+        lib = hip_lib.load()
+        ws = torch.empty(lib.vrwkv_add_ln_ws_floats(ntok, C), dtype=torch.float32, device=xn.device)
+        rc = lib.vrwkv_add_ln_bwd_bf16(ntok, C, dy.data_ptr(), _p(d_xn), xn.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                       wc.data_ptr(), dx.data_ptr(), dwb.data_ptr(), ws.data_ptr(), _stream(xn))
+        hip_lib.check(rc, "vrwkv_add_ln_bwd_bf16")
+        dwb = dwb.to(wc.dtype)
+        return dx, (dx if ctx.has_delta else None), dwb[0], dwb[1], None
+
+
+def add_ln(x, delta, ln):
+    """Residual add + nn.LayerNorm `ln` in one kernel: returns (x + delta, ln(x + delta)); delta may be None."""
+    if delta is None:
+        return x, _AddLN.apply(x, None, ln.weight, ln.bias, ln.eps)
+    return _AddLN.apply(x, delta, ln.weight, ln.bias, ln.eps)
+
+
+def add_ln_supported(x):
+    return x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 64 == 0 and x.shape[-1] <= 8192
+
+
+def blocks_forward(rwkv, x):
+    """All Blocks + ln_out with the residual adds fused into the LayerNorms (same math as Block.forward chained,
+    src/model.py:247-254,313-318): the residual stream is carried as (x, pending delta)."""
+    x = rwkv.blocks[0].ln0(x)
+    v_first = torch.empty_like(x)
+    delta = None
+    for block in rwkv.blocks:
+        x, h = add_ln(x, delta, block.ln1)
+        att_out, v_first = block.att(h, v_first)
+        x, h = add_ln(x, att_out, block.ln2)
+        delta = block.ffn(h)
+    _, h = add_ln(x, delta, rwkv.ln_out)
+    return h
+
+
 def tmix_forward(m, x, v_first):
     """RWKV_Tmix_x070.forward (src/model.py:163-195) with the glue fused; `m` is the module."""
     B, T, C = x.shape

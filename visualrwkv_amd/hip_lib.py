@@ -10,7 +10,7 @@ import os
 
 from .build import LIB_PATH
 
-_c_int, _c_void_p = ctypes.c_int, ctypes.c_void_p
+_c_int, _c_void_p, _c_long, _c_float = ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_float
 
 # symbol -> (restype, argtypes); must list every function include/visualrwkv_hip.h declares
 PROTOTYPES = {
@@ -18,6 +18,9 @@ PROTOTYPES = {
     "vrwkv_strerror": (ctypes.c_char_p, [_c_int]),
     "vrwkv_wkv7_forward_bf16": (_c_int, [_c_int] * 3 + [_c_void_p] * 10),
     "vrwkv_wkv7_backward_bf16": (_c_int, [_c_int] * 3 + [_c_void_p] * 16),
+    "vrwkv_add_ln_ws_floats": (_c_long, [_c_long, _c_int]),
+    "vrwkv_add_ln_fwd_bf16": (_c_int, [_c_long, _c_int, _c_float] + [_c_void_p] * 9),
+    "vrwkv_add_ln_bwd_bf16": (_c_int, [_c_long, _c_int] + [_c_void_p] * 10),
     "vrwkv_wkv7_step_bf16": (_c_int, [_c_int] * 2 + [_c_void_p] * 9),
     "vrwkv_wkv7_set_forward_variant": (_c_int, [_c_int]),
     "vrwkv_wkv7_set_backward_variant": (_c_int, [_c_int]),
