@@ -202,3 +202,10 @@ DEVFN unsigned long long clock64_() { return 0; }
 DEVFN void block_sync() { emu::block_barrier(); }
 DEVFN void block_sync_lds() { emu::block_barrier(); }
 DEVFN void wave_lds_fence() { emu::wave_barrier(); }
+DEVFN void lds_flag_add(unsigned* cnt) {
+    emu::wave_barrier();
+    if ((emu::flat_tid() & 63) == 0) *(volatile unsigned*)cnt += 1;
+}
+DEVFN void lds_flag_wait(unsigned* cnt, unsigned target) {
+    while ((int)(*(volatile unsigned*)cnt - target) < 0) emu::yield();
+}

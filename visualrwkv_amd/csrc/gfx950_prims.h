@@ -158,6 +158,25 @@ DEVFN void block_sync() { __syncthreads(); }
 // Global loads stay tracked by the compiler (it waits before their first use); global stores need no ordering
 // against other waves of the workgroup here.
 DEVFN void block_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// One-directional hand-off between groups of waves of a workgroup through a monotonically increasing counter in
+// LDS -- s_barrier makes EVERY wave of the workgroup wait, a flag only the waves that consume the data (gfx950 has no
+// named barriers).  lds_flag_add: whole wave calls it after its LDS writes; lane 0 increments (the LDS unit executes a
+// wave's instructions in issue order, so the increment lands after the wave's writes).  lds_flag_wait: spin until
+// the counter reaches `target` (wrap-safe compare); the reads issued afterwards see the producers' writes.
+DEVFN void lds_flag_add(unsigned* cnt) {
+    const unsigned a = (unsigned)(uintptr_t)cnt;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(a), "v"(1u) : "memory");
+}
+DEVFN void lds_flag_wait(unsigned* cnt, unsigned target) {
+    const unsigned a = (unsigned)(uintptr_t)cnt;
+    for (;;) {
+        unsigned v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+        if ((int)(__builtin_amdgcn_readfirstlane(v) - target) >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
 // LDS ops of one wave execute in order; this only stops the compiler from moving LDS accesses
 // across the point where lanes exchange data through LDS.
 DEVFN void wave_lds_fence() {

@@ -149,10 +149,10 @@ int vrwkv_wkv7_profile_bf16(int backward, int B, int T, int H, const void* w, co
         if (backward == 0 && g_fwd_variant == 3) {
             hipLaunchKernelGGL(wkv7c::fwd_kernel_t<true>, grid, dim3(256), 0, st, p);
         } else {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::fwd_kernel_v3<true>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::fwd_kernel_v3<true, false, 1>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsF));
             if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL(wkv7c::fwd_kernel_v3<true>, grid, dim3(512), sizeof(wkv7c::LdsF), st, p);
+            hipLaunchKernelGGL((wkv7c::fwd_kernel_v3<true, false, 1>), grid, dim3(512), sizeof(wkv7c::LdsF), st, p);
         }
     } else {
         wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,

@@ -33,7 +33,7 @@ struct BufF {
     float scf[2][L][SF];          // 0 M_qa  1 T    ; fp32 [t][s]
     float cl[N];                  // c_L[j]
 };
-struct LdsF { BufF b[2]; };
+struct LdsF { BufF b[2]; unsigned prep_done; unsigned pad_[3]; };   // prep_done: producer-only hand-off counter
 
 // D = P*Q on the f32 matrix core: pt = P^T in C layout (A operand), qc = Q in C layout (B operand);
 // MFMA #r contracts the k-slots (g) <-> index 4g+r, which is exactly register r of both fragments.
@@ -172,14 +172,18 @@ __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
         };
         RawChunk rc;
         fetch(rc, 0);
+        block_sync_lds();                               // prep_done is zeroed
         for (int c = 0; c <= nchunk; ++c) {            // iteration c produces chunk c (one ahead of the consumers)
             if (c < nchunk) {
                 RawChunk cur = rc;
                 if (c + 1 < nchunk) fetch(rc, c + 1);
                 prep_v3(lds.b[c & 1], cur, pw, lane);
+                lds_flag_add(&lds.prep_done);
             }
             WKV_STAMP(0)
-            block_sync_lds();                           // A
+            // A: the scores need the operand images of all four producer waves.  Only the producers wait (a counter,
+            // not s_barrier): the consumers' second half does not depend on anything produced in this iteration.
+            if (c < nchunk) lds_flag_wait(&lds.prep_done, 4u * (unsigned)(c + 1));
             WKV_STAMP(1)
             if (c < nchunk) scores_v3(lds.b[c & 1], pw, lane);
             WKV_STAMP(2)
@@ -203,8 +207,9 @@ __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
     const unsigned s_off = WIDE ? (unsigned)(4 * g + (c16 & 3)) * N + 16u * wave + (c16 & ~3)   // s[j = 16jb+4g+(c16&3)][i..i+3]
                                 : (unsigned)(4 * g) * N + 16u * wave + c16;
 
-    block_sync_lds();      // A  (producers fill buffer 0)
-    block_sync_lds();      // B
+    if (tid == 0) lds.prep_done = 0u;
+    block_sync_lds();      // prep_done is zeroed
+    block_sync_lds();      // B  (producers have filled buffer 0)
     for (int c = 0; c < nchunk; ++c) {
         const BufF& B = lds.b[c & 1];
         WKV_STAMP(0)
@@ -246,7 +251,6 @@ __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) Y[r] += (Ya[r] + Yb[r]) + Yc[r];
         WKV_STAMP(1)
-        block_sync_lds();                                        // A
         WKV_STAMP(2)
         {
             float* sa_c = psa + (size_t)c * L * ts;
@@ -264,6 +268,7 @@ __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
                 }
             }
         }
+        WKV_STAMP(3)
         // S_L^T = diag(c_L) S0^T + [Ab^T | Kb^T] [SA ; V]
         uint2 sah, sal;
         split4(SA, sah, sal);
@@ -289,11 +294,11 @@ __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
                 for (int r = 0; r < 4; ++r) s_c[s_off + (unsigned)(16 * jb + r) * N] = acc[r];
             }
         }
-        WKV_STAMP(3)
-        block_sync_lds();                                        // B
         WKV_STAMP(4)
+        block_sync_lds();                                        // B
+        WKV_STAMP(5)
     }
-    WKV_STAMP_FLUSH(0, 0, 5)
+    WKV_STAMP_FLUSH(0, 0, 6)
 }
 
 }  // namespace wkv7c
