@@ -34,14 +34,19 @@ int emu_wkv7_backward(int B, int T, int H, const void* w, const void* q, const v
 
 int emu_wkv7_backward_chunked(int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
                               const void* z, const void* a, const void* dy, const float* s, const float* sa,
-                              void* dw, void* dq, void* dk, void* dv, void* dz, void* da) {
+                              void* dw, void* dq, void* dk, void* dv, void* dz, void* da, int mode) {
+    // mode -1: 4-wave kernel (wkv7_chunked_bwd.h); 0..3: 8-wave kernel, bit 0 = hand-off counters, bit 1 = bf16x3 doubling
     wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                     (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
                     (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
     static_assert(sizeof(wkv7c::LdsB) <= 160 * 1024, "LDS budget");
     static_assert(sizeof(wkv7c::LdsB3) <= 160 * 1024, "LDS budget");
-    if (getenv("EMU_BWD_V2")) emu::launch(dim3((unsigned)(B * H)), dim3(256), [&] { wkv7c::bwd_kernel_t<false>(p); });
-    else emu::launch(dim3((unsigned)(B * H)), dim3(512), [&] { wkv7c::bwd_kernel_v3<false>(p); });
+    const dim3 grid((unsigned)(B * H));
+    if (mode < 0) emu::launch(grid, dim3(256), [&] { wkv7c::bwd_kernel_t<false>(p); });
+    else if (mode == 0) emu::launch(grid, dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 0>(p); });
+    else if (mode == 1) emu::launch(grid, dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 1>(p); });
+    else if (mode == 2) emu::launch(grid, dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 2>(p); });
+    else emu::launch(grid, dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 3>(p); });
     return (int)sizeof(wkv7c::LdsB3);
 }
 

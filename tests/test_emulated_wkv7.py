@@ -37,6 +37,22 @@ def test_backward(emu_lib):
         assert rel_rms(o.float(), r.float()) < 1e-3, name
 
 
+@pytest.mark.parametrize("mode", [-1, 0, 1, 2, 3])
+def test_backward_chunked(emu_lib, mode):
+    """Chunked MFMA backward kernels run lane-exactly on the host: the 4-wave kernel (-1) and the 8-wave
+    producer/consumer kernel with workgroup barriers or LDS hand-off counters (bit 0) and f32 / bf16x3 doubling (bit 1)."""
+    B, T, H = 1, 48, 2
+    w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=7 + mode)
+    _, s, sa = wkv7_c.forward(w, q, k, v, z, a)
+    ref = wkv7_c.backward(w, q, k, v, z, a, dy, s, sa)
+    outs = [torch.zeros_like(w) for _ in range(6)]
+    lds = emu_lib.emu_wkv7_backward_chunked(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(dy), P(s), P(sa),
+                                            *[P(o) for o in outs], mode)
+    assert 0 < lds <= 160 * 1024
+    for name, o, r in zip(["dw", "dq", "dk", "dv", "dz", "da"], outs, ref):
+        assert rel_rms(o.float(), r.float()) < 1e-3, (name, mode)
+
+
 @pytest.mark.parametrize("D,L", [(64, 70), (72, 48)])
 def test_attention_forward(emu_lib, D, L):
     """ViT attention kernel (csrc/attention_kernels.h) vs fp32 softmax attention; q/k/v are strided slices of one

@@ -3,7 +3,10 @@
 // Same algorithm as wkv7_chunked_bwd.h (see its header for the math); the schedule is rebuilt from the phase
 // times measured on MI355X for the 4-wave kernel (per chunk, B=8: prep 3.4k cycles, scores 1.9k, i-split 2.4k,
 // score gradients 0.7k, j-split 2.5k, tail 1.3k, all back to back on one wave per SIMD).
-// One workgroup = 8 waves per (b,h); chunks are walked from last to first; three LDS-only barriers per chunk:
+// One workgroup = 8 waves per (b,h); chunks are walked from last to first; three hand-off points per chunk.  They are
+// counters in LDS (lds_flag_add / lds_flag_wait), not s_barrier: a wave waits only for the waves whose data it needs,
+// e.g. the consumers never wait for the producers' first segment (measured with workgroup barriers: consumers idle
+// 0.8k of 9k cycles per chunk at X, producers 1.6k at Y and Z).
 //
 //              segment 1                    X   segment 2                         Y   segment 3            Z
 //   producers  prep(c-1), first part            prep(c-1) rest, dM(c) gradients      scores(c-1): M^T, T
@@ -20,6 +23,7 @@
 #pragma once
 #include <gfx950_prims.h>
 #include <wkv7_chunked_bwd.h>
+#include <wkv7_fwd_v3.h>     // regmm_bf16x3
 
 namespace wkv7c {
 
@@ -40,6 +44,8 @@ struct LdsB3 {
     uint16_t drT[2][N][JT];         // dR^T hi,lo  [i][t]
     uint16_t dsc[8][2][L][SS];      // dM images (producers -> consumers)
     float glast[N];
+    unsigned cphase, pphase;        // hand-off counters: +1 per consumer / producer wave at the end of each segment
+    unsigned pad_[2];
     float res[3][L][RS];            // dAh dKh G bounced from C layout to "token per lane" for the tail; dZt and dQt
                                     // use the dr/drT area, which is dead in segment 3 (res_mat below)
 };
@@ -91,6 +97,7 @@ DEVFN void bwd_prep_b(BufB& B, const RawB& raw, int pw, int lane, const float* a
     split4(sav, hh, ll); st8(&B.ti[2][c16][c0], hh); st8(&B.ti[3][c16][c0], ll);
 }
 
+template <bool DBL_BF16>
 DEVFN void bwd_scores(LdsB3& lds, BufB& B, int pw, int lane) {
     const int c16 = lane & 15, g = lane >> 4;
     if (pw != 0) {
@@ -113,16 +120,10 @@ DEVFN void bwd_scores(LdsB3& lds, BufB& B, int pw, int lane) {
         }
 #pragma unroll
         for (int level = 0; level < 3; ++level) {
-            f32x4 XTn = zero4(), Xn = X, D = zero4();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) XTn = mfma_16x16x4_f32(X[r], XT[r], XTn);        // (X^T)^2
-            if (level < 2) {
-                Xn = zero4();
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Xn = mfma_16x16x4_f32(XT[r], X[r], Xn);      // X^2
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) D = mfma_16x16x4_f32(XTn[r], Tc[r], D);          // X_k T
+            const f32x4 XTn = DBL_BF16 ? regmm_bf16x3(X, XT) : regmm_f32(X, XT);         // (X^T)^2
+            f32x4 Xn = X;
+            if (level < 2) Xn = DBL_BF16 ? regmm_bf16x3(XT, X) : regmm_f32(XT, X);        // X^2
+            const f32x4 D = DBL_BF16 ? regmm_bf16x3(XTn, Tc) : regmm_f32(XTn, Tc);        // X_k T
 #pragma unroll
             for (int r = 0; r < 4; ++r) Tc[r] += D[r];
             X = Xn; XT = XTn;
@@ -162,8 +163,11 @@ DEVFN void bwd_dscores(LdsB3& lds, const BufB& B, int pw, int lane) {
 }
 
 // ------------------------------------------------------------------------------------------ kernel
-template <bool PROF>
+// MODE bit 0: hand-off counters instead of workgroup barriers; bit 1: T doubling on the bf16 matrix core (bf16x3)
+// instead of the f32 one.  Both are kept selectable for same-process A/B timing (benchmarks/wkv7_micro.py).
+template <bool PROF, int MODE = 0>
 __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
+    constexpr bool FLAGS = (MODE & 1) != 0;
     LdsB3& lds = *reinterpret_cast<LdsB3*>(dyn_lds());
     const int T = p.T, H = p.H;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -173,6 +177,12 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
     const unsigned ts = (unsigned)(H * N);
     const size_t head_base = ((size_t)(blockIdx.x / H) * T * H + (blockIdx.x % H)) * N;
     WKV_STAMP_DECL
+    // hand-off points: counters (FLAGS) or, at the three places marked X / Y / Z, workgroup barriers
+    auto wait_c = [&](unsigned target) { if (FLAGS) lds_flag_wait(&lds.cphase, target); };
+    auto wait_p = [&](unsigned target) { if (FLAGS) lds_flag_wait(&lds.pphase, target); };
+    auto done_c = [&]() { if (FLAGS) lds_flag_add(&lds.cphase); };
+    auto done_p = [&]() { if (FLAGS) lds_flag_add(&lds.pphase); };
+    auto bar = [&]() { if (!FLAGS) block_sync_lds(); };
 
     if (wave >= 4) {
         // ================================================================== producers
@@ -187,37 +197,55 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
         };
         RawB raw;
         fetch(raw, nchunk - 1);
-        // prologue: produce the last chunk completely (prep + scores); consumers idle through X,Y,Z
+        block_sync_lds();                                   // counters are zeroed
+        // prologue ("iteration -1"): produce the last chunk completely; 3 increments per wave like every iteration
         {
             float kab[4], kkb[4];
             RawB cur = raw;
             if (nchunk > 1) fetch(raw, nchunk - 2);
             bwd_prep_a(lds, lds.b[(nchunk - 1) & 1], cur, pw, lane, kab, kkb);
+            done_p();
             bwd_prep_b(lds.b[(nchunk - 1) & 1], cur, pw, lane, kab, kkb);
-            block_sync_lds();   // X
-            block_sync_lds();   // Y
-            bwd_scores(lds, lds.b[(nchunk - 1) & 1], pw, lane);
-            block_sync_lds();   // Z
+            done_p();
+            wait_p(8u);                                     // every producer's operand images are in LDS
+            bar(); bar();                                   // X, Y
+            bwd_scores<(MODE & 2) != 0>(lds, lds.b[(nchunk - 1) & 1], pw, lane);
+            done_p();
+            bar();                                          // Z
         }
-        for (int c = nchunk - 1; c >= 0; --c) {      // consumers process chunk c, producers build chunk c-1
+        unsigned it = 0;                                    // iteration k: consumers process chunk c, producers build c-1
+        for (int c = nchunk - 1; c >= 0; --c, ++it) {
             const bool more = c > 0;
             float kab[4], kkb[4];
             RawB cur = raw;
+            // P1: operand images of chunk c-1.  `opnd` is free once every producer finished the previous scores; the
+            // target buffer b[(c-1)&1] once every consumer finished the previous chunk.
+            wait_p(12u * (it + 1));
+            wait_c(12u * it);
+            WKV_STAMP(0)
             if (more) {
                 if (c > 1) fetch(raw, c - 2);
                 bwd_prep_a(lds, lds.b[(c - 1) & 1], cur, pw, lane, kab, kkb);
             }
-            WKV_STAMP(0)
-            block_sync_lds();   // X : consumers' dR(c) is in LDS
+            done_p();
+            bar();                                          // X
             WKV_STAMP(1)
+            // P2: rest of the images (nobody reads them before the next iteration), then the score gradients of
+            // chunk c, which need the consumers' dR(c)
             if (more) bwd_prep_b(lds.b[(c - 1) & 1], cur, pw, lane, kab, kkb);
-            bwd_dscores(lds, lds.b[c & 1], pw, lane);
             WKV_STAMP(2)
-            block_sync_lds();   // Y : dM(c) images ready for the consumers
+            wait_c(12u * it + 4u);
+            wait_p(12u * (it + 1) + 4u);                    // keeps "count >= base + 4s  =>  all waves finished segment s"
             WKV_STAMP(3)
-            if (more) bwd_scores(lds, lds.b[(c - 1) & 1], pw, lane);
+            bwd_dscores(lds, lds.b[c & 1], pw, lane);
+            done_p();
+            // P3: scores of chunk c-1 from all four producers' operand images (waiting for the P2 count also covers P1)
+            wait_p(12u * (it + 1) + 8u);
+            bar();                                          // Y
             WKV_STAMP(4)
-            block_sync_lds();   // Z
+            if (more) bwd_scores<(MODE & 2) != 0>(lds, lds.b[(c - 1) & 1], pw, lane);
+            done_p();
+            bar();                                          // Z
             WKV_STAMP(5)
         }
         WKV_STAMP_FLUSH(256, 8, 6)
@@ -248,9 +276,17 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
     const unsigned row_off = (unsigned)c16 * ts + (unsigned)c0;
     const unsigned dv_off = (unsigned)(4 * g) * ts + 16u * wave + c16;
 
-    block_sync_lds(); block_sync_lds(); block_sync_lds();      // prologue X, Y, Z
-    for (int c = nchunk - 1; c >= 0; --c) {
+    if (tid == 0) { lds.cphase = 0u; lds.pphase = 0u; }
+    block_sync_lds();                                          // counters are zeroed
+    bar(); bar(); bar();                                       // prologue X, Y, Z
+    unsigned it = 0;
+    for (int c = nchunk - 1; c >= 0; --c, ++it) {
         const BufB& B = lds.b[c & 1];
+        // C1 may start when buffer c&1 is complete (producers' previous iteration) and every consumer has left the
+        // previous tail (its bounce strips alias dr/drT, which this segment overwrites)
+        wait_p(12u * (it + 1));
+        wait_c(12u * it);
+        WKV_STAMP(5)
         const size_t cbase = head_base + (size_t)c * L * ts;
         // ---------------------------------------------------------------- segment 1: i-split (i = 16w + c16)
         uint2 rh, rl;
@@ -291,8 +327,10 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
                 dS1[jb] = acc;
             }
         }
+        done_c();
         WKV_STAMP(0)
-        block_sync_lds();       // X
+        wait_c(12u * it + 4u);                              // X: every consumer's dR(c) is in LDS
+        bar();
         WKV_STAMP(1)
         // ---------------------------------------------------------------- segment 2: j-split against S0 / dU (j = 16w + c16)
         const int j = 16 * wave + c16;
@@ -344,8 +382,11 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
                 SL[ib] = S0[ib];
             }
         }
+        done_c();
         WKV_STAMP(2)
-        block_sync_lds();       // Y
+        wait_c(12u * it + 8u);                              // Y: nobody reads dr/drT any more (bounce strips alias them)
+        wait_p(12u * (it + 1) + 8u);                        //    and the dM(c) images are ready
+        bar();
         WKV_STAMP(3)
         // ---------------------------------------------------------------- segment 3: dM products + tail
         {
@@ -413,9 +454,9 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
             *reinterpret_cast<uint2*>(p.dz + o) = make_uint2(cvt_pk_bf16(dz[0], dz[1]), cvt_pk_bf16(dz[2], dz[3]));
             *reinterpret_cast<uint2*>(p.da + o) = make_uint2(cvt_pk_bf16(da[0], da[1]), cvt_pk_bf16(da[2], da[3]));
         }
+        done_c();
+        bar();                                              // Z
         WKV_STAMP(4)
-        block_sync_lds();       // Z
-        WKV_STAMP(5)
     }
     WKV_STAMP_FLUSH(0, 0, 6)
 }

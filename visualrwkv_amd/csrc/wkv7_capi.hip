@@ -13,6 +13,7 @@ namespace {
 
 int g_fwd_variant = -1;
 int g_bwd_variant = -1;
+constexpr int BWD_V3_DEFAULT_MODE = 2;    // same-process A/B on MI355X (benchmarks/wkv7_ab.py): counters +1..3 % slower, bf16x3 doubling -1 %
 
 inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 
@@ -50,7 +51,7 @@ int vrwkv_wkv7_set_forward_variant(int variant) {
 }
 
 int vrwkv_wkv7_set_backward_variant(int variant) {
-    if (variant > 2) return VRWKV_EINVAL;
+    if (variant > 5) return VRWKV_EINVAL;
     g_bwd_variant = variant;
     return VRWKV_OK;
 }
@@ -110,15 +111,23 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H, const void* w, const void* q, 
     const dim3 grid((unsigned)((long)B * H));
     if (g_bwd_variant == 0) {
         hipLaunchKernelGGL((wkv7::bwd_kernel<8>), grid, dim3(256), 0, st, p);
-    } else if (g_bwd_variant < 0 || g_bwd_variant == 2) {
-        static bool attr3_set = false;
-        if (!attr3_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::bwd_kernel_v3<false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsB3));
-            if (e != hipSuccess) return (int)e;
-            attr3_set = true;
-        }
-        hipLaunchKernelGGL(wkv7c::bwd_kernel_v3<false>, grid, dim3(512), sizeof(wkv7c::LdsB3), st, p);
+    } else if (g_bwd_variant < 0 || (g_bwd_variant >= 2 && g_bwd_variant <= 5)) {
+        // 2: barriers + f32 doubling, 3: hand-off counters, 4: barriers + bf16x3 doubling, 5: both
+        const int mode = g_bwd_variant < 0 ? BWD_V3_DEFAULT_MODE : g_bwd_variant - 2;
+        auto launch = [&](auto kern, bool& attr) -> int {
+            if (!attr) {        // > 64 KB of LDS needs the opt-in once per process
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)sizeof(wkv7c::LdsB3));
+                if (e != hipSuccess) return (int)e;
+                attr = true;
+            }
+            hipLaunchKernelGGL(kern, grid, dim3(512), sizeof(wkv7c::LdsB3), st, p);
+            return 0;
+        };
+        static bool at0 = false, at1 = false, at2 = false, at3 = false;
+        int e = mode == 0 ? launch(&wkv7c::bwd_kernel_v3<false, 0>, at0) : mode == 1 ? launch(&wkv7c::bwd_kernel_v3<false, 1>, at1)
+              : mode == 2 ? launch(&wkv7c::bwd_kernel_v3<false, 2>, at2) : launch(&wkv7c::bwd_kernel_v3<false, 3>, at3);
+        if (e) return e;
     } else {
         static bool attr_set = false;     // > 64 KB of LDS needs the opt-in once per process
         if (!attr_set) {
@@ -164,10 +173,10 @@ int vrwkv_wkv7_profile_bf16(int backward, int B, int T, int H, const void* w, co
             if (e != hipSuccess) return (int)e;
             hipLaunchKernelGGL(wkv7c::bwd_kernel_t<true>, grid, dim3(256), sizeof(wkv7c::LdsB), st, p);
         } else {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::bwd_kernel_v3<true>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::bwd_kernel_v3<true, BWD_V3_DEFAULT_MODE>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsB3));
             if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL(wkv7c::bwd_kernel_v3<true>, grid, dim3(512), sizeof(wkv7c::LdsB3), st, p);
+            hipLaunchKernelGGL((wkv7c::bwd_kernel_v3<true, BWD_V3_DEFAULT_MODE>), grid, dim3(512), sizeof(wkv7c::LdsB3), st, p);
         }
     }
     return finish_launch();

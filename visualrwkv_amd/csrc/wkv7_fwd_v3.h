@@ -43,6 +43,17 @@ DEVFN f32x4 regmm_f32(f32x4 pt, f32x4 qc) {
     for (int r = 0; r < 4; ++r) acc = mfma_16x16x4_f32(pt[r], qc[r], acc);
     return acc;
 }
+// The same product on the bf16 matrix core with split operands (P_h Q_h + P_h Q_l + P_l Q_h, ~2^-16 relative):
+//   MFMA 1:  A = [P_h | P_h],  B = [Q_h ; Q_l]       MFMA 2:  A = [P_l | 0],  B = [Q_h ; 0]
+// (k-slots 0-3 and 4-7 of lane group g both stand for index 4g+e).  2 x 16 cycles instead of 4 dependent f32 MFMAs
+// of 32-40 cycles: the nilpotent doubling for T is the critical path of the producers' second half.
+DEVFN f32x4 regmm_bf16x3(f32x4 pt, f32x4 qc) {
+    uint2 ph, pl, qh, ql;
+    split4(pt, ph, pl);
+    split4(qc, qh, ql);
+    const f32x4 acc = mfma_16x16x32_bf16(mk8(ph, ph), mk8(qh, ql), zero4());
+    return mfma_16x16x32_bf16(mk8(pl.x, pl.y, 0u, 0u), mk8(qh.x, qh.y, 0u, 0u), acc);
+}
 // acc += M[row c16][s] * B[s][col] with M an fp32 [t][s] image in LDS and B a C-layout fragment
 DEVFN f32x4 mm_f32_image(f32x4 acc, const float (*M)[SF], int c16, int g, f32x4 bfrag) {
     const float4 m = *reinterpret_cast<const float4*>(&M[c16][4 * g]);
@@ -133,10 +144,10 @@ DEVFN void scores_v3(BufF& B, int pw, int lane) {
         }
 #pragma unroll
         for (int level = 0; level < 3; ++level) {
-            const f32x4 X2 = regmm_f32(XT, X);
+            const f32x4 X2 = regmm_bf16x3(XT, X);
             f32x4 XT2 = XT;
-            if (level < 2) XT2 = regmm_f32(X, XT);
-            const f32x4 D = regmm_f32(X2, TT);
+            if (level < 2) XT2 = regmm_bf16x3(X, XT);
+            const f32x4 D = regmm_bf16x3(X2, TT);
 #pragma unroll
             for (int r = 0; r < 4; ++r) TT[r] += D[r];
             X = X2; XT = XT2;
