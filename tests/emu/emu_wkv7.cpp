@@ -18,7 +18,9 @@ int emu_wkv7_forward(int B, int T, int H, const void* w, const void* q, const vo
     else if (variant == 1) emu::launch(grid, dim3(128), [&] { wkv7::fwd_kernel<8, 16>(p); });
     else if (variant == 2) emu::launch(grid, dim3(256), [&] { wkv7::fwd_kernel<4, 16>(p); });
     else if (variant == 3) emu::launch(grid, dim3(256), [&] { wkv7c::fwd_kernel_t<false>(p); });
-    else emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false>(p); });
+    else if (variant == 4) emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false>(p); });                       // wide stores
+    else if (variant == 5) emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1>(p); });             // narrow stores
+    else emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1, 2, true>(p); });                      // + prefetch 2, DPP suffix
     return 0;
 }
 

@@ -64,6 +64,7 @@ DEVFN f32x4 mm_f32_image(f32x4 acc, const float (*M)[SF], int c16, int g, f32x4 
     return acc;
 }
 
+template <bool SFX>
 DEVFN void prep_v3(BufF& B, const RawChunk& rc, int pw, int lane) {
     const int t = lane & 15, g = lane >> 4, j0 = 16 * pw + 4 * g;
     float wr[4], q[4], k[4], z[4], a[4];
@@ -74,8 +75,15 @@ DEVFN void prep_v3(BufF& B, const RawChunk& rc, int pw, int lane) {
         const float lw = -fast_exp(wr[e]);
         float x = lw;
         x += dpp_shr<1>(x); x += dpp_shr<2>(x); x += dpp_shr<4>(x); x += dpp_shr<8>(x);
-        const float tot = lane_bcast(x, (lane & 48) | 15);
-        const float c = fast_exp(x), cp = fast_exp(x - lw), ic = fast_exp(-x), cb = fast_exp(tot - x);
+        float rest;                                    // sum of log-decays of the later tokens of the chunk
+        if (SFX) {                                     // exclusive suffix scan with DPP row shifts (no LDS round trip)
+            float y = lw;
+            y += dpp_shl<1>(y); y += dpp_shl<2>(y); y += dpp_shl<4>(y); y += dpp_shl<8>(y);
+            rest = y - lw;
+        } else {
+            rest = lane_bcast(x, (lane & 48) | 15) - x;
+        }
+        const float c = fast_exp(x), cp = fast_exp(x - lw), ic = fast_exp(-x), cb = fast_exp(rest);
         zt[e] = z[e] * cp; qt[e] = q[e] * c; ah[e] = a[e] * ic; kh[e] = k[e] * ic;
         ab[e] = a[e] * cb; kb[e] = k[e] * cb; cend[e] = c;
     }
@@ -156,7 +164,9 @@ DEVFN void scores_v3(BufF& B, int pw, int lane) {
     }
 }
 
-template <bool PROF, bool WIDE = true, int PRIO = 1>
+// PF: chunks of input prefetch held in registers by the producers (HBM latency under load exceeds one chunk time);
+// SFX: decay suffix by DPP scan instead of ds_bpermute.
+template <bool PROF, bool WIDE = true, int PRIO = 1, int PF = 1, bool SFX = false>
 __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
     LdsF& lds = *reinterpret_cast<LdsF*>(dyn_lds());
     const int T = p.T, H = p.H;
@@ -181,14 +191,18 @@ __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
             rc.k = *reinterpret_cast<const uint2*>(pk + o); rc.z = *reinterpret_cast<const uint2*>(pz + o);
             rc.a = *reinterpret_cast<const uint2*>(pa + o); rc.v = *reinterpret_cast<const uint2*>(pv + o);
         };
-        RawChunk rc;
+        RawChunk rc, rc2;
         fetch(rc, 0);
+        if (PF > 1 && nchunk > 1) fetch(rc2, 1);
         block_sync_lds();                               // prep_done is zeroed
         for (int c = 0; c <= nchunk; ++c) {            // iteration c produces chunk c (one ahead of the consumers)
             if (c < nchunk) {
                 RawChunk cur = rc;
-                if (c + 1 < nchunk) fetch(rc, c + 1);
-                prep_v3(lds.b[c & 1], cur, pw, lane);
+                if (PF > 1) {
+                    rc = rc2;
+                    if (c + 2 < nchunk) fetch(rc2, c + 2);
+                } else if (c + 1 < nchunk) fetch(rc, c + 1);
+                prep_v3<SFX>(lds.b[c & 1], cur, pw, lane);
                 lds_flag_add(&lds.prep_done);
             }
             WKV_STAMP(0)
