@@ -7,7 +7,7 @@ from benchmarks.wkv7_micro import synth_inputs
 from visualrwkv_amd import hip_lib
 
 FWD = ["c_top", "c_main1", "c_waitA", "c_store_y_sa", "c_supdate_store_s", "c_waitB", "-", "-", "p_prep", "p_waitA", "p_scores", "p_waitB"]
-BWD = ["c_isplit", "c_waitX", "c_jsplit1", "c_waitY", "c_jsplit2_tail", "c_waitZ", "-", "-", "p_prepA", "p_waitX", "p_prepB_dM", "p_waitY", "p_scores", "p_waitZ"]
+BWD = ["c_isplit", "c_waitX", "c_jsplit", "c_waitY", "c_tail_waitZ", "c_start", "-", "-", "p_start", "p_prepA_waitX", "p_prepB", "p_flagwait", "p_dM_waitY", "p_scores_waitZ"]
 
 def run(B=8, T=2624, H=32):
     lib = hip_lib.load()

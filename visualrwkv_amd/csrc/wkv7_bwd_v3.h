@@ -59,11 +59,12 @@ DEVFN float* res_mat(LdsB3& lds, int m) {       // m: 0 dZt, 1 dQt, 2 dAh, 3 dKh
 struct RawB { uint2 w, q, k, z, a, v, dy; float4 sa; };
 
 // ------------------------------------------------------------------------------------------ producers
-DEVFN void bwd_prep_a(LdsB3& lds, BufB& B, const RawB& raw, int pw, int lane, float* keep_ab, float* keep_kb) {
+struct KeepB { float ab[4], kb[4], ah[4], kh[4]; };     // values prep_a computes and prep_b stores (balances the segments)
+DEVFN void bwd_prep_a(LdsB3& lds, BufB& B, const RawB& raw, int pw, int lane, KeepB& keep) {
     const int c16 = lane & 15, g = lane >> 4, c0 = 16 * pw + 4 * g;
     float wr[4], q[4], k[4], z[4], a[4];
     unpack4(raw.w, wr); unpack4(raw.q, q); unpack4(raw.k, k); unpack4(raw.z, z); unpack4(raw.a, a);
-    float zt[4], qt[4], ah[4], kh[4], cend[4];
+    float zt[4], qt[4], cend[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float lw = -fast_exp(wr[e]);
@@ -71,25 +72,27 @@ DEVFN void bwd_prep_a(LdsB3& lds, BufB& B, const RawB& raw, int pw, int lane, fl
         x += dpp_shr<1>(x); x += dpp_shr<2>(x); x += dpp_shr<4>(x); x += dpp_shr<8>(x);
         const float tot = lane_bcast(x, (lane & 48) | 15);
         const float cc = fast_exp(x), cp = fast_exp(x - lw), ic = fast_exp(-x), cb = fast_exp(tot - x);
-        zt[e] = z[e] * cp; qt[e] = q[e] * cc; ah[e] = a[e] * ic; kh[e] = k[e] * ic;
-        keep_ab[e] = a[e] * cb; keep_kb[e] = k[e] * cb; cend[e] = cc;
+        zt[e] = z[e] * cp; qt[e] = q[e] * cc; keep.ah[e] = a[e] * ic; keep.kh[e] = k[e] * ic;
+        keep.ab[e] = a[e] * cb; keep.kb[e] = k[e] * cb; cend[e] = cc;
     }
     uint2 hh, ll;
     split4(zt, hh, ll); st8(&lds.opnd[0][c16][c0], hh); st8(&lds.opnd[1][c16][c0], ll);
     st_b16x4_T(B.trn[0], c0, c16, hh); st_b16x4_T(B.trn[1], c0, c16, ll);
     split4(qt, hh, ll); st8(&lds.opnd[2][c16][c0], hh); st8(&lds.opnd[3][c16][c0], ll);
     st_b16x4_T(B.trn[2], c0, c16, hh); st_b16x4_T(B.trn[3], c0, c16, ll);
-    split4(ah, hh, ll); st8(&lds.opnd[4][c16][c0], hh); st8(&lds.opnd[5][c16][c0], ll);
-    st_b16x4_T(B.trn[4], c0, c16, hh); st_b16x4_T(B.trn[5], c0, c16, ll);
-    split4(kh, hh, ll); st8(&lds.opnd[6][c16][c0], hh); st8(&lds.opnd[7][c16][c0], ll);
-    st_b16x4_T(B.trn[6], c0, c16, hh); st_b16x4_T(B.trn[7], c0, c16, ll);
     if (c16 == 15) *reinterpret_cast<float4*>(&B.cl[c0]) = make_float4(cend[0], cend[1], cend[2], cend[3]);
 }
-DEVFN void bwd_prep_b(BufB& B, const RawB& raw, int pw, int lane, const float* ab, const float* kb) {
+// The Ah / Kh images are first read by the scores (third segment) and by the consumers of the NEXT iteration, so they
+// are written here, in the producers' short second segment, not in prep_a (first segment: 3.1k vs the consumers' 2.4k).
+DEVFN void bwd_prep_b(LdsB3& lds, BufB& B, const RawB& raw, int pw, int lane, const KeepB& keep) {
     const int c16 = lane & 15, g = lane >> 4, c0 = 16 * pw + 4 * g;
     uint2 hh, ll;
-    split4(ab, hh, ll); st8(&B.ab[0][c16][c0], hh); st8(&B.ab[1][c16][c0], ll);
-    split4(kb, hh, ll); st8(&B.ab[2][c16][c0], hh); st8(&B.ab[3][c16][c0], ll);
+    split4(keep.ah, hh, ll); st8(&lds.opnd[4][c16][c0], hh); st8(&lds.opnd[5][c16][c0], ll);
+    st_b16x4_T(B.trn[4], c0, c16, hh); st_b16x4_T(B.trn[5], c0, c16, ll);
+    split4(keep.kh, hh, ll); st8(&lds.opnd[6][c16][c0], hh); st8(&lds.opnd[7][c16][c0], ll);
+    st_b16x4_T(B.trn[6], c0, c16, hh); st_b16x4_T(B.trn[7], c0, c16, ll);
+    split4(keep.ab, hh, ll); st8(&B.ab[0][c16][c0], hh); st8(&B.ab[1][c16][c0], ll);
+    split4(keep.kb, hh, ll); st8(&B.ab[2][c16][c0], hh); st8(&B.ab[3][c16][c0], ll);
     st8(&B.ti[0][c16][c0], raw.v);
     st8(&B.ti[1][c16][c0], raw.dy);
     st_b16x4_T(B.dyT, c0, c16, raw.dy);
@@ -200,12 +203,12 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
         block_sync_lds();                                   // counters are zeroed
         // prologue ("iteration -1"): produce the last chunk completely; 3 increments per wave like every iteration
         {
-            float kab[4], kkb[4];
+            KeepB keep;
             RawB cur = raw;
             if (nchunk > 1) fetch(raw, nchunk - 2);
-            bwd_prep_a(lds, lds.b[(nchunk - 1) & 1], cur, pw, lane, kab, kkb);
+            bwd_prep_a(lds, lds.b[(nchunk - 1) & 1], cur, pw, lane, keep);
             done_p();
-            bwd_prep_b(lds.b[(nchunk - 1) & 1], cur, pw, lane, kab, kkb);
+            bwd_prep_b(lds, lds.b[(nchunk - 1) & 1], cur, pw, lane, keep);
             done_p();
             wait_p(8u);                                     // every producer's operand images are in LDS
             bar(); bar();                                   // X, Y
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
         unsigned it = 0;                                    // iteration k: consumers process chunk c, producers build c-1
         for (int c = nchunk - 1; c >= 0; --c, ++it) {
             const bool more = c > 0;
-            float kab[4], kkb[4];
+            KeepB keep;
             RawB cur = raw;
             // P1: operand images of chunk c-1.  `opnd` is free once every producer finished the previous scores; the
             // target buffer b[(c-1)&1] once every consumer finished the previous chunk.
@@ -225,14 +228,14 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
             WKV_STAMP(0)
             if (more) {
                 if (c > 1) fetch(raw, c - 2);
-                bwd_prep_a(lds, lds.b[(c - 1) & 1], cur, pw, lane, kab, kkb);
+                bwd_prep_a(lds, lds.b[(c - 1) & 1], cur, pw, lane, keep);
             }
             done_p();
             bar();                                          // X
             WKV_STAMP(1)
             // P2: rest of the images (nobody reads them before the next iteration), then the score gradients of
             // chunk c, which need the consumers' dR(c)
-            if (more) bwd_prep_b(lds.b[(c - 1) & 1], cur, pw, lane, kab, kkb);
+            if (more) bwd_prep_b(lds, lds.b[(c - 1) & 1], cur, pw, lane, keep);
             WKV_STAMP(2)
             wait_c(12u * it + 4u);
             wait_p(12u * (it + 1) + 4u);                    // keeps "count >= base + 4s  =>  all waves finished segment s"
