@@ -47,6 +47,43 @@ def test_single_process_matches_torch_adamw():
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
 
 
+def test_gradient_gather_modes_agree_and_unused_parameters_get_zero():
+    """zero_grad(set_to_none=True) (bucket-wise multi-tensor gather of autograd's gradient tensors) and
+    set_to_none=False (in-place accumulation into the zeroed flat buffer) give the same update; a parameter that
+    received no gradient in a step is treated as zero gradient, not as last step's."""
+    from visualrwkv_amd.dp import Zero1Engine
+
+    class WithUnused(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.body = _model()
+            self.unused = nn.Parameter(torch.ones(7, 5))
+            self.use_it = True
+
+        def forward(self, x):
+            y = self.body(x)
+            return y + self.unused.sum() * 1e-3 if self.use_it else y
+
+    x, y = _data()
+    results = []
+    for set_to_none in (True, False):
+        torch.manual_seed(0)
+        m = WithUnused()
+        eng = Zero1Engine(m, lr=1e-2, weight_decay=0.0, grad_clip=0.0, bucket_mb=0.001)
+        for step in range(4):
+            m.use_it = step == 0                      # only the first step produces a gradient for `unused`
+            eng.zero_grad(set_to_none=set_to_none)
+            _loss(m, x, y).backward()
+            eng.step()
+            if step >= 1:
+                assert float(m.unused.grad.abs().sum()) == 0.0
+            for p in m.parameters():                 # .grad is (again) a view of the flat buffer
+                assert p.grad.data_ptr() >= eng.flat_grad.data_ptr()
+        results.append([p.detach().clone() for p in m.parameters()])
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
+
+
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
