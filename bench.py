@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--grad-cp", type=int, default=0)
     ap.add_argument("--fused", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-tuning", type=int, default=1)         # library-GEMM kernel choice from the shipped TunableOp file
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,6 +119,10 @@ def main():
 
     from visualrwkv_amd import build, wkv7
     build.build()
+    n_tuned = 0
+    if a.gemm_tuning:
+        from visualrwkv_amd.gemm_tuning import enable_tuned_gemms
+        n_tuned = enable_tuned_gemms()
     from visualrwkv_amd.dp import Zero1Engine
     from visualrwkv_amd.visual import VisualRWKV
     towers = tuple(t for t in a.towers.split(",") if t)
@@ -172,7 +177,8 @@ def main():
                                    f"full train step (fwd+bwd+ZeRO-1 AdamW)", "model": f"VisualRWKV-7 {a.model}",
                        "global_batch": world * a.micro_bsz, "seq_len": a.ctx_len, "parallelism": f"dp{world}",
                        "grad_cp": a.grad_cp, "fused_elementwise": bool(a.fused), "loss": float(loss.detach()),
-                       "micro_bsz": a.micro_bsz, "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1)},
+                       "micro_bsz": a.micro_bsz, "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+                       "gemm_kernels": f"TunableOp file, {n_tuned} shapes" if n_tuned else "library default"},
         }
         # roofline of the dominant hot-path kernel (WKV7 backward), HIP events on the launch stream
         kinds = {}
