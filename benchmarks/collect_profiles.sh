@@ -7,7 +7,12 @@ timeout 600 python bench.py --steps 5 --warmup 2 2>&1 | grep -v amdgpu.ids | tai
 cd /tmp; export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/step -o step -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/step.log 2>&1
 cd $R
-bash benchmarks/wkv7_pmc.sh 16 gpurun_out/$TAG/pmc_b16 -1 > $O/wkv7_pmc_b16.txt 2>&1
-bash benchmarks/wkv7_pmc.sh 8 gpurun_out/$TAG/pmc_b8 -1 > $O/wkv7_pmc_b8.txt 2>&1
+PMC_MERGE=1 bash benchmarks/wkv7_pmc.sh 16 gpurun_out/$TAG/pmc_b16 -1 > $O/wkv7_pmc_b16.txt 2>&1
+PMC_MERGE=1 bash benchmarks/wkv7_pmc.sh 8 gpurun_out/$TAG/pmc_b8 -1 > $O/wkv7_pmc_b8.txt 2>&1
+cp profiles/wkv7_pmc.json $O/wkv7_pmc.json
+# the N>1 code path (hooks, side stream, RCCL reduce-scatter / all-gather) on the one GPU of this box
+VRWKV_FORCE_COLLECTIVES=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
+    bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | grep -v amdgpu.ids | tail -1 > $O/bench_rccl_1rank.json
+python benchmarks/wkv7_phases.py 8 2>&1 | tail -1 > $O/wkv7_phases_b8.json
 python benchmarks/wkv7_micro.py --B 8 16 32 --iters 20 2>&1 | grep -v amdgpu > $O/wkv7_micro.jsonl
 cat $O/pytest_gpu.txt; cut -c1-600 $O/bench.json
