@@ -50,6 +50,19 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H,
                              void* dw, void* dq, void* dk, void* dv, void* dz, void* da,
                              void* stream);
 
+/* WKV6 (BASELINE config 4): replaces cuda_forward / cuda_backward of VisualRWKV-v6/v6.0/cuda/wkv6_cuda.cu:229-242 as bound
+ * by cuda/wkv6_op.cpp:8-13 (forward(B,T,C,H,r,k,v,w,u,y), backward(B,T,C,H,r,k,v,w,u,gy,gr,gk,gv,gw,gu)).
+ * r,k,v,y,gy,gr,gk,gv,gw: (B,T,C) bf16; ew: (B,T,C) f32 = -exp(w_raw) as WKV_6.forward computes it (src/model.py:62);
+ * u: (C) bf16; gu: (B,C) bf16, summed over the batch by the caller (src/model.py:84); C == 64*H; any T >= 1.
+ * s_ckpt: vrwkv_wkv6_ckpt_floats(B,T,H) floats of chunk-start states -- optional output of the forward (NULL for
+ * inference), required input of the backward (the reference re-sweeps the sequence five times instead). */
+long vrwkv_wkv6_ckpt_floats(int B, int T, int H);
+int vrwkv_wkv6_forward_bf16(int B, int T, int C, int H, const void* r, const void* k, const void* v, const float* ew,
+                            const void* u, void* y, float* s_ckpt, void* stream);
+int vrwkv_wkv6_backward_bf16(int B, int T, int C, int H, const void* r, const void* k, const void* v, const float* ew,
+                             const void* u, const void* gy, const float* s_ckpt, void* gr, void* gk, void* gv, void* gw,
+                             void* gu, void* stream);
+
 /* Residual add + LayerNorm in one pass (Block.forward: x = x + att(ln1(x)); x = x + ffn(ln2(x)), and ln_out --
  * VisualRWKV-v7/v7.00/src/model.py:247-254,318; the reference runs a bf16 add followed by nn.LayerNorm).
  *   fwd: xn = bf16(x + delta) (delta may be NULL: no add, xn not written), y = LayerNorm(xn; w, b, eps); mean/rstd

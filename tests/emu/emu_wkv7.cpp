@@ -6,6 +6,7 @@
 #include <wkv7_chunked_bwd.h>
 #include <wkv7_fwd_v3.h>
 #include <wkv7_bwd_v3.h>
+#include <wkv6_chunked.h>
 
 extern "C" {
 
@@ -50,6 +51,21 @@ int emu_wkv7_backward_chunked(int B, int T, int H, const void* w, const void* q,
     else if (mode == 2) emu::launch(grid, dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 2>(p); });
     else emu::launch(grid, dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 3>(p); });
     return (int)sizeof(wkv7c::LdsB3);
+}
+
+int emu_wkv6_forward(int B, int T, int H, const void* r, const void* k, const void* v, const float* ew, const void* u,
+                     void* y, float* s) {
+    wkv6c::Fwd6Args p{T, H, (const uint16_t*)r, (const uint16_t*)k, (const uint16_t*)v, ew, (const uint16_t*)u, (uint16_t*)y, s};
+    emu::launch(dim3((unsigned)(B * H)), dim3(256), [&] { wkv6c::fwd6_kernel(p); });
+    return (int)sizeof(wkv6c::Lds6F);
+}
+
+int emu_wkv6_backward(int B, int T, int H, const void* r, const void* k, const void* v, const float* ew, const void* u,
+                      const void* gy, const float* s, void* gr, void* gk, void* gv, void* gw, void* gu) {
+    wkv6c::Bwd6Args p{T, H, (const uint16_t*)r, (const uint16_t*)k, (const uint16_t*)v, ew, (const uint16_t*)u,
+                      (const uint16_t*)gy, s, (uint16_t*)gr, (uint16_t*)gk, (uint16_t*)gv, (uint16_t*)gw, (uint16_t*)gu};
+    emu::launch(dim3((unsigned)(B * H)), dim3(256), [&] { wkv6c::bwd6_kernel(p); });
+    return (int)sizeof(wkv6c::Lds6B);
 }
 
 }  // extern "C"

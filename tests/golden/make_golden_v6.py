@@ -1,0 +1,121 @@
+"""Generate tests/golden/v6_ref.pt by importing the reference's own RWKV-6 Python
+(VisualRWKV-v6/v6.0/src/model.py: RWKV_Tmix_x060, RWKV_CMix_x060, WKV_6, RUN_CUDA_RWKV6) in this container.
+
+As for the v7 fixtures, third-party packages the image lacks get inert stand-ins and `cpp_extension.load` returns an
+object whose forward / backward are the repo's WKV6 oracle (the reference has no CPU kernel; its wrapper asserts bf16,
+so the time-mix fixture is a bf16 run).  Only tensors are stored, nothing of the reference's source.
+
+Run where /root/reference exists:   python tests/golden/make_golden_v6.py
+"""
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/VisualRWKV-v6/v6.0"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from oracle.wkv6_oracle import wkv6_autograd, wkv6_naive  # noqa: E402
+
+
+class OracleWkv6Module:
+    """Stands in for the JIT-built extension module `wkv6_cuda` (model.py:40): same two entry points."""
+
+    @staticmethod
+    def forward(B, T, C, H, r, k, v, ew, u, y):
+        w_raw = torch.log(-ew)                                   # the kernels receive ew = -exp(w)
+        f = lambda x: x.float().view(B, T, H, C // H)
+        out, _ = wkv6_naive(f(r), f(k), f(v), w_raw.view(B, T, H, C // H), u.float().view(H, C // H))
+        y.copy_(out.reshape(B, T, C).to(y.dtype))
+
+    @staticmethod
+    def backward(B, T, C, H, r, k, v, ew, u, gy, gr, gk, gv, gw, gu):
+        N = C // H
+        w_raw = torch.log(-ew.double())
+        f = lambda x: x.double().view(B, T, H, N)
+        for b in range(B):                                       # gu is per sample in the reference (B,C)
+          with torch.enable_grad():                              # the reference wrapper calls us under no_grad
+            _, g = wkv6_autograd(f(r)[b:b + 1], f(k)[b:b + 1], f(v)[b:b + 1], w_raw.view(B, T, H, N)[b:b + 1],
+                                 u.double().view(H, N), f(gy)[b:b + 1])
+          for dst, src in zip((gr, gk, gv, gw), g[:4]):
+              dst[b].copy_(src.reshape(T, C).to(dst.dtype))
+          gu[b].copy_(g[4].reshape(C).to(gu.dtype))
+
+
+def install_stubs():
+    pl = types.ModuleType("pytorch_lightning")
+    pl.LightningModule = nn.Module
+    pl.__version__ = "1.9.5"
+    plu = types.ModuleType("pytorch_lightning.utilities")
+    plu.rank_zero_info = lambda *a, **k: None
+    plu.rank_zero_only = lambda f: f
+    pls = types.ModuleType("pytorch_lightning.strategies")
+    pls.DeepSpeedStrategy = type("DeepSpeedStrategy", (), {})
+    ds = types.ModuleType("src.dataset")
+    ds.IGNORE_INDEX, ds.IMAGE_TOKEN_INDEX = -100, -200
+    sys.modules.update({"pytorch_lightning": pl, "pytorch_lightning.utilities": plu, "pytorch_lightning.strategies": pls,
+                        "src.dataset": ds})
+    import torch.utils.cpp_extension as ce
+    ce.load = lambda *a, **k: OracleWkv6Module
+    os.environ["RWKV_JIT_ON"] = "0"
+    os.environ["RWKV_HEAD_SIZE_A"] = "64"
+    os.environ["RWKV_CTXLEN"] = "64"
+
+
+def main():
+    install_stubs()
+    from src import model as ref
+    g = torch.Generator().manual_seed(11)
+    args = SimpleNamespace(n_embd=128, dim_att=128, n_layer=4, head_size_a=64, head_size_divisor=8, dim_ffn=448)
+    out = {"args": vars(args), "layer_id": 1}
+    tmix = ref.RWKV_Tmix_x060(args, 1)
+    cmix = ref.RWKV_CMix_x060(args, 1)
+    with torch.no_grad():
+        for m in (tmix, cmix):
+            for p in m.parameters():
+                if float(p.abs().sum()) == 0.0:                 # zero-initialised LoRA halves / projections
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+        for lin in (tmix.receptance, tmix.key, tmix.value, tmix.output, tmix.gate, cmix.key, cmix.receptance, cmix.value):
+            lin.weight.copy_(torch.randn(lin.weight.shape, generator=g) * 0.08)
+    out["tmix_state"] = {k: v.detach().clone() for k, v in tmix.state_dict().items()}
+    out["cmix_state"] = {k: v.detach().clone() for k, v in cmix.state_dict().items()}
+    x = torch.randn(2, 24, 128, generator=g)
+    out["x"] = x
+    # channel-mix in fp32
+    with torch.no_grad():
+        out["cmix_y_fp32"] = cmix(x)
+    # time-mix in bf16 (the wrapper asserts bf16), forward and backward through the reference's WKV_6
+    tb = tmix.bfloat16()
+    xb = x.bfloat16().requires_grad_(True)
+    y = tb(xb)
+    gy = torch.randn(y.shape, generator=g).bfloat16()
+    y.backward(gy)
+    out["tmix_y_bf16"] = y.detach()
+    out["tmix_gy"] = gy
+    out["tmix_gx_bf16"] = xb.grad.detach()
+    out["tmix_grads_bf16"] = {k: p.grad.detach().clone() for k, p in tb.named_parameters()
+                              if k in ("time_faaaa", "time_decay", "time_maa_w", "key.weight")}
+    # the op itself as the reference wrapper drives it: RUN_CUDA_RWKV6 on random bf16 inputs
+    B, T, C, H = 2, 24, 128, 2
+    uni = lambda *s, lo=-1.0, hi=1.0: (torch.rand(*s, generator=g) * (hi - lo) + lo).bfloat16()
+    r, k, v = (uni(B, T, C).requires_grad_(True) for _ in range(3))
+    w = uni(B, T, C, lo=-8.0, hi=1.0).requires_grad_(True)
+    u = uni(H, C // H).requires_grad_(True)
+    yy = ref.RUN_CUDA_RWKV6(B, T, C, H, r, k, v, w, u)
+    gyy = uni(B, T, C)
+    yy.backward(gyy)
+    out["op"] = {"r": r.detach(), "k": k.detach(), "v": v.detach(), "w": w.detach(), "u": u.detach(), "gy": gyy,
+                 "y": yy.detach(), "gr": r.grad, "gk": k.grad, "gv": v.grad, "gw": w.grad, "gu": u.grad}
+    path = os.path.join(HERE, "v6_ref.pt")
+    torch.save(out, path)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,132 @@
+"""WKV6 on the MI355X: torch.ops.wkv6 / WKV_6 / RUN_CUDA_RWKV6 (HIP kernels behind the C-ABI) against the oracle and
+the fixtures recorded through the reference's own wrappers; RWKV_Tmix_x060 against the reference module's bf16 run."""
+import os
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from oracle.wkv6_oracle import make_inputs6, wkv6_autograd
+from oracle.wkv7_oracle import rel_rms
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "v6_ref.pt")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return torch.load(GOLD)
+
+
+def _run(r, k, v, w, u, gy):
+    from visualrwkv_amd import wkv6
+    B, T, H, N = r.shape
+    C = H * N
+    ins = [x.cuda().reshape(B, T, C).clone().requires_grad_(True) for x in (r, k, v, w)] + [u.cuda().clone().requires_grad_(True)]
+    y = wkv6.RUN_CUDA_RWKV6(B, T, C, H, *ins)
+    y.backward(gy.cuda().reshape(B, T, C))
+    torch.cuda.synchronize()
+    return y.detach().cpu(), [x.grad.cpu() for x in ins]
+
+
+@pytest.mark.parametrize("B,T,H", [(1, 1, 1), (2, 16, 2), (2, 37, 3), (1, 400, 5), (3, 129, 2)])
+def test_op_matches_oracle(B, T, H):
+    r, k, v, w, u, gy = make_inputs6(B, T, H, seed=B * 1000 + T)
+    y, (gr, gk, gv, gw, gu) = _run(r, k, v, w, u, gy)
+    y_ref, g_ref = wkv6_autograd(r, k, v, w, u, gy)
+    C = H * 64
+    assert rel_rms(y.double(), y_ref.reshape(B, T, C)) < 4e-3                 # one bf16 rounding
+    for a, ref, n in zip((gr, gk, gv, gw), g_ref[:4], "rkvw"):
+        assert rel_rms(a.double(), ref.reshape(B, T, C)) < 4e-3, n
+    assert rel_rms(gu.double(), g_ref[4]) < 1e-2                               # per-sample bf16 rows summed, as the reference
+
+
+def test_strong_decays_stay_finite():
+    """Per-token log decays down to -e^2.3 = -10: the midpoint-referenced exponents stay in range."""
+    r, k, v, w, u, gy = make_inputs6(1, 64, 2, seed=3, w_lo=-2.0, w_hi=2.3)
+    y, grads = _run(r, k, v, w, u, gy)
+    y_ref, g_ref = wkv6_autograd(r, k, v, w, u, gy)
+    assert torch.isfinite(y).all() and all(torch.isfinite(g).all() for g in grads)
+    assert rel_rms(y.double(), y_ref.reshape(1, 64, 128)) < 4e-3
+    assert rel_rms(grads[3].double(), g_ref[3].reshape(1, 64, 128)) < 6e-3
+
+
+def test_reference_wrapper_fixture(gold):
+    op = gold["op"]
+    B, T, C = op["r"].shape
+    H = op["u"].shape[0]
+    f = lambda x: x.view(B, T, H, C // H)
+    y, (gr, gk, gv, gw, gu) = _run(f(op["r"]), f(op["k"]), f(op["v"]), f(op["w"]), op["u"], f(op["gy"]))
+    assert rel_rms(y.float(), op["y"].float()) < 6e-3                          # both sides rounded to bf16
+    for a, n in ((gr, "gr"), (gk, "gk"), (gv, "gv"), (gw, "gw")):
+        assert rel_rms(a.float(), op[n].float()) < 6e-3, n
+    assert rel_rms(gu.float(), op["gu"].float()) < 1.5e-2
+
+
+def test_raw_ops_with_reference_schema():
+    """torch.ops.wkv6.forward / backward take exactly the arguments of cuda/wkv6_op.cpp:8-13 (no saved state)."""
+    B, T, H = 2, 48, 2
+    C = H * 64
+    r, k, v, w, u, gy = [x.cuda() for x in make_inputs6(B, T, H, seed=9)]
+    r, k, v, w, gy = [x.reshape(B, T, C) for x in (r, k, v, w, gy)]
+    ew = (-torch.exp(w.float())).contiguous()
+    y = torch.empty_like(r)
+    torch.ops.wkv6.forward(B, T, C, H, r, k, v, ew, u, y)
+    outs = [torch.empty_like(r) for _ in range(4)]
+    gu = torch.empty(B, C, dtype=torch.bfloat16, device="cuda")
+    torch.ops.wkv6.backward(B, T, C, H, r, k, v, ew, u, gy, *outs, gu)
+    f = lambda x: x.cpu().view(B, T, H, 64)
+    y_ref, g_ref = wkv6_autograd(f(r), f(k), f(v), f(w), u.cpu(), f(gy))
+    assert rel_rms(y.cpu().double(), y_ref.reshape(B, T, C)) < 4e-3
+    for a, ref in zip(outs, g_ref[:4]):
+        assert rel_rms(a.cpu().double(), ref.reshape(B, T, C)) < 4e-3
+    assert rel_rms(gu.cpu().double().sum(0).view(H, 64), g_ref[4]) < 1e-2
+
+
+def test_op_rejects_bad_arguments():
+    from visualrwkv_amd import wkv6
+    B, T, H = 1, 16, 1
+    r = torch.zeros(B, T, 64, dtype=torch.bfloat16, device="cuda")
+    u = torch.zeros(1, 64, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(ValueError):
+        torch.ops.wkv6.forward(B, T, 64, H, r, r, r, r, u, torch.empty_like(r))           # w must be the f32 log decay
+    with pytest.raises(ValueError):
+        torch.ops.wkv6.forward(B, T, 64, H, r.float(), r, r, r.float(), u, torch.empty_like(r))
+    with pytest.raises(Exception):
+        wkv6.forward_hip(B, T, 128, H, r, r, r, r.float(), u, torch.empty_like(r))         # C != 64 H
+    with pytest.raises(AssertionError):
+        wkv6.RUN_CUDA_RWKV6(B, T, 64, H, r.float(), r, r, r, u)
+
+
+def test_config4_shape_properties():
+    """cfg4 shape (T = 2624, H = 64): causality (bit-exact) and exact x2 scaling of v."""
+    from visualrwkv_amd import wkv6
+    B, T, H = 1, 2624, 64
+    C = H * 64
+    g = torch.Generator(device="cuda").manual_seed(1)
+    uni = lambda *s, lo=-1.0, hi=1.0: (torch.rand(*s, device="cuda", generator=g) * (hi - lo) + lo).bfloat16()
+    r, k, v = uni(B, T, C), uni(B, T, C), uni(B, T, C)
+    w, u = uni(B, T, C, lo=-8.0, hi=1.0), uni(H, 64)
+    y = wkv6.RUN_CUDA_RWKV6(B, T, C, H, r, k, v, w, u)
+    y2 = wkv6.RUN_CUDA_RWKV6(B, T, C, H, r, k, (v.float() * 2).bfloat16(), w, u)
+    assert torch.equal(y2.float(), y.float() * 2)
+    k2 = k.clone()
+    k2[:, 2000:] = 0
+    y3 = wkv6.RUN_CUDA_RWKV6(B, T, C, H, r, k2, v, w, u)
+    assert torch.equal(y3[:, :2000], y[:, :2000]) and not torch.equal(y3[:, 2000:], y[:, 2000:])
+
+
+def test_tmix_x060_against_reference_module(gold):
+    from visualrwkv_amd.rwkv6 import RWKV_Tmix_x060
+    args = SimpleNamespace(**gold["args"])
+    m = RWKV_Tmix_x060(args, gold["layer_id"])
+    m.load_state_dict(gold["tmix_state"])
+    m = m.bfloat16().cuda()
+    x = gold["x"].bfloat16().cuda().requires_grad_(True)
+    y = m(x)
+    y.backward(gold["tmix_gy"].cuda())
+    assert rel_rms(y.float().cpu(), gold["tmix_y_bf16"].float()) < 1e-2
+    assert rel_rms(x.grad.float().cpu(), gold["tmix_gx_bf16"].float()) < 2e-2
+    named = dict(m.named_parameters())
+    for k, gr in gold["tmix_grads_bf16"].items():
+        assert rel_rms(named[k].grad.float().cpu(), gr.float()) < 3e-2, k

@@ -18,6 +18,9 @@ PROTOTYPES = {
     "vrwkv_strerror": (ctypes.c_char_p, [_c_int]),
     "vrwkv_wkv7_forward_bf16": (_c_int, [_c_int] * 3 + [_c_void_p] * 10),
     "vrwkv_wkv7_backward_bf16": (_c_int, [_c_int] * 3 + [_c_void_p] * 16),
+    "vrwkv_wkv6_ckpt_floats": (_c_long, [_c_int] * 3),
+    "vrwkv_wkv6_forward_bf16": (_c_int, [_c_int] * 4 + [_c_void_p] * 8),
+    "vrwkv_wkv6_backward_bf16": (_c_int, [_c_int] * 4 + [_c_void_p] * 13),
     "vrwkv_add_ln_ws_floats": (_c_long, [_c_long, _c_int]),
     "vrwkv_add_ln_fwd_bf16": (_c_int, [_c_long, _c_int, _c_float] + [_c_void_p] * 9),
     "vrwkv_add_ln_bwd_bf16": (_c_int, [_c_long, _c_int] + [_c_void_p] * 10),

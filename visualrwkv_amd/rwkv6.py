@@ -1,0 +1,106 @@
+"""Host-side mirror of the reference's RWKV-6 modules (VisualRWKV-v6/v6.0/src/model.py:92-226): same class names,
+constructor arguments, parameter names and initialisers (=> the reference's state-dict keys), forward through
+RUN_CUDA_RWKV6.  BASELINE config 4 (VisualRWKV-6 7B) runs the same Block/RWKV/VisualRWKV scaffolding around these."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import wkv6 as _wkv6
+
+
+def time_shift(x):
+    """nn.ZeroPad2d((0, 0, 1, -1)): x[t-1], zero at t = 0."""
+    return F.pad(x, (0, 0, 1, -1))
+
+
+class RWKV_Tmix_x060(nn.Module):
+    """RWKV-6 time-mix with the 5-way data-dependent token-shift LoRA (model.py:92-194)."""
+
+    def __init__(self, args, layer_id):
+        super().__init__()
+        self.args = args
+        self.layer_id = layer_id
+        self.head_size = args.head_size_a
+        self.n_head = args.dim_att // self.head_size
+        assert args.dim_att % self.n_head == 0
+        C, A = args.n_embd, args.dim_att
+        with torch.no_grad():
+            r01 = layer_id / (args.n_layer - 1)
+            r10 = 1.0 - (layer_id / args.n_layer)
+            ddd = (torch.arange(C, dtype=torch.float32) / C).view(1, 1, C)
+            self.time_maa_x = nn.Parameter(1.0 - torch.pow(ddd, r10))
+            self.time_maa_w = nn.Parameter(1.0 - torch.pow(ddd, r10))
+            self.time_maa_k = nn.Parameter(1.0 - torch.pow(ddd, r10))
+            self.time_maa_v = nn.Parameter(1.0 - (torch.pow(ddd, r10) + 0.3 * r01))
+            self.time_maa_r = nn.Parameter(1.0 - torch.pow(ddd, 0.5 * r10))
+            self.time_maa_g = nn.Parameter(1.0 - torch.pow(ddd, 0.5 * r10))
+            d_mix = 64 if C >= 4096 else 32
+            self.time_maa_w1 = nn.Parameter(torch.zeros(C, d_mix * 5))
+            self.time_maa_w2 = nn.Parameter(torch.zeros(5, d_mix, C).uniform_(-0.01, 0.01))
+            n = torch.arange(A, dtype=torch.float32)
+            self.time_decay = nn.Parameter((-6 + 5 * (n / (A - 1)) ** (0.7 + 1.3 * r01)).reshape(1, 1, A))
+            d_decay = 128 if C >= 4096 else 64
+            self.time_decay_w1 = nn.Parameter(torch.zeros(C, d_decay))
+            self.time_decay_w2 = nn.Parameter(torch.zeros(d_decay, A).uniform_(-0.01, 0.01))
+            zigzag = ((torch.arange(A) + 1) % 3 - 1).float() * 0.1
+            self.time_faaaa = nn.Parameter((r01 * (1 - n / (A - 1)) + zigzag).reshape(self.n_head, self.head_size))
+        self.receptance = nn.Linear(C, A, bias=False)
+        self.key = nn.Linear(C, A, bias=False)
+        self.value = nn.Linear(C, A, bias=False)
+        self.output = nn.Linear(A, C, bias=False)
+        self.gate = nn.Linear(C, A, bias=False)
+        self.ln_x = nn.GroupNorm(self.n_head, A, eps=(1e-5) * (args.head_size_divisor ** 2))
+
+    def mix(self, x):
+        B, T, C = x.size()
+        xx = time_shift(x) - x
+        xxx = x + xx * self.time_maa_x
+        xxx = torch.tanh(xxx @ self.time_maa_w1).view(B * T, 5, -1).transpose(0, 1)
+        xxx = torch.bmm(xxx, self.time_maa_w2).view(5, B, T, -1)
+        mw, mk, mv, mr, mg = xxx.unbind(dim=0)
+        xw = x + xx * (self.time_maa_w + mw)
+        xk = x + xx * (self.time_maa_k + mk)
+        xv = x + xx * (self.time_maa_v + mv)
+        xr = x + xx * (self.time_maa_r + mr)
+        xg = x + xx * (self.time_maa_g + mg)
+        r = self.receptance(xr)
+        k = self.key(xk)
+        v = self.value(xv)
+        g = F.silu(self.gate(xg))
+        w = self.time_decay + torch.tanh(xw @ self.time_decay_w1) @ self.time_decay_w2
+        return r, k, v, g, w
+
+    def forward(self, x, wkv=None):
+        B, T, C = x.size()
+        r, k, v, g, w = self.mix(x)
+        run = wkv if wkv is not None else _wkv6.RUN_CUDA_RWKV6
+        y = run(B, T, C, self.n_head, r, k, v, w, self.time_faaaa)
+        y = self.ln_x(y.view(B * T, C)).view(B, T, C)
+        return self.output(y * g)
+
+
+class RWKV_CMix_x060(nn.Module):
+    """RWKV-6 channel-mix with the receptance gate (model.py:198-226)."""
+
+    def __init__(self, args, layer_id):
+        super().__init__()
+        self.args = args
+        self.layer_id = layer_id
+        C = args.n_embd
+        with torch.no_grad():
+            r10 = 1.0 - (layer_id / args.n_layer)
+            ddd = (torch.arange(C, dtype=torch.float32) / C).view(1, 1, C)
+            self.time_maa_k = nn.Parameter(1.0 - torch.pow(ddd, r10))
+            self.time_maa_r = nn.Parameter(1.0 - torch.pow(ddd, r10))
+        self.key = nn.Linear(C, args.dim_ffn, bias=False)
+        self.receptance = nn.Linear(C, C, bias=False)
+        self.value = nn.Linear(args.dim_ffn, C, bias=False)
+
+    def forward(self, x):
+        xx = time_shift(x) - x
+        xk = x + xx * self.time_maa_k
+        xr = x + xx * self.time_maa_r
+        k = torch.relu(self.key(xk)) ** 2
+        return torch.sigmoid(self.receptance(xr)) * self.value(k)
