@@ -76,6 +76,16 @@ int vrwkv_add_ln_fwd_bf16(long ntok, int C, float eps, const void* x, const void
 int vrwkv_add_ln_bwd_bf16(long ntok, int C, const void* dy, const void* dres, const void* xn, const float* mean,
                           const float* rstd, const void* w, void* dx, float* dwb, float* ws, void* stream);
 
+/* Cross-entropy over the vocabulary + L2Wrap gradient (training_step / L2Wrap, VisualRWKV-v7/v7.00/src/model.py:418-434,
+ * 257-271), one pass over the (nrows, V) bf16 logits per direction.  labels: int64 per row, the already SHIFTED target
+ * (-100 = ignored).  fwd writes per row: loss (0 for ignored rows), max, log-sum-exp, first arg-max.
+ * bwd: dlogits = row_w (softmax - onehot(label)) + onehot(argmax) * max * l2_factor;  row_w carries the upstream
+ * gradient and the per-sample normalisation and is 0 for ignored rows.  V % 8 == 0. */
+int vrwkv_ce_fwd_bf16(long nrows, int V, const void* logits, const long* labels, float* row_loss, float* row_max,
+                      float* row_lse, int* row_argmax, void* stream);
+int vrwkv_ce_bwd_bf16(long nrows, int V, const void* logits, const long* labels, const float* row_w, const float* row_max,
+                      const float* row_lse, const int* row_argmax, float l2_factor, void* dlogits, void* stream);
+
 /* WKV7 single-token step with carried state (stateful generation; the reference re-runs the whole forward per new
  * token, VisualRWKV-v7/v7.00/src/model.py:513-529).  w..a, y: (B,H,64) bf16; state: (B,H,64,64) f32, S[i][j] with
  * i = value row, j = key column, updated in place.  (The training op's checkpoint `s` holds S^T.) */

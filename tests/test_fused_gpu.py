@@ -187,6 +187,29 @@ def test_add_ln(ntok, C, has_delta):
     _check([ln.weight.grad, ln.bias.grad], [rx[1].grad, rx[2].grad], tol=2e-3)
 
 
+@pytest.mark.parametrize("B,T,V", [(2, 9, 512), (3, 33, 65536), (1, 16, 1000)])
+def test_fused_cross_entropy_and_l2wrap(B, T, V):
+    """csrc/loss_fused.hip vs the eager statement of training_step + L2Wrap (src/model.py:418-434,257-271)."""
+    from visualrwkv_amd import fused
+    from visualrwkv_amd.visual import VisualRWKV
+    g = torch.Generator().manual_seed(B * 100 + T)
+    logits = (torch.randn(B, T, V, generator=g) * 2).bfloat16().cuda()
+    targets = torch.randint(0, V, (B, T), generator=g).cuda()
+    targets[:, : T // 3] = -100
+    targets[0, -2] = -100
+    if B > 2:
+        targets[2] = -100                                             # a sample without any valid label
+    a = logits.clone().requires_grad_(True)
+    loss = fused.loss_from_logits(a, targets, -100)
+    (loss * 1.5).backward()
+    b = logits.clone().float().requires_grad_(True)                   # eager reference in fp32
+    ref = VisualRWKV.loss_from_logits(b, targets)
+    (ref * 1.5).backward()
+    assert abs(float(loss) - float(ref)) < 1e-2 * abs(float(ref)) + 1e-3
+    # the L2Wrap term is not scaled by the upstream gradient; its arg-max may differ only between exact ties
+    assert rel_rms(a.grad.float().cpu(), b.grad.cpu()) < 1e-2
+
+
 def test_fused_rejects_wrong_inputs():
     from visualrwkv_amd import fused
     x = torch.randn(1, 4, 128, device="cuda")          # fp32: must raise, not fall back

@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libvisualrwkv_hip.so")
 ARCH = "gfx950"
 
-SOURCES = ["wkv7_capi.hip", "probe.hip", "fused_ops.hip", "tmix_fused.hip", "attention.hip", "wkv7_step.hip", "ln_fused.hip", "wkv6_capi.hip"]
+SOURCES = ["wkv7_capi.hip", "probe.hip", "fused_ops.hip", "tmix_fused.hip", "attention.hip", "wkv7_step.hip", "ln_fused.hip", "wkv6_capi.hip", "loss_fused.hip"]
 
 
 def hipcc() -> str:

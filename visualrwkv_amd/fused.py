@@ -299,6 +299,51 @@ def blocks_forward(rwkv, x):
     return h
 
 
+class _FusedCE(torch.autograd.Function):
+    """training_step's loss (shifted CE, per-sample sum / max(valid,1), batch mean) with L2Wrap's gradient term
+    (src/model.py:418-434,257-271) -- csrc/loss_fused.hip."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, ignore_index):
+        B, T, V = logits.shape
+        logits = logits.contiguous()
+        _chk(logits)
+        labels = torch.full((B, T), ignore_index, dtype=torch.long, device=logits.device)
+        labels[:, :-1] = targets[:, 1:]                       # row (b,t) predicts token t+1; the last row has no target
+        labels = torch.where(labels == ignore_index, torch.full_like(labels, -100), labels)
+        valid = (labels >= 0).sum(1).clamp(min=1)
+        n = B * T
+        dev = logits.device
+        row_loss, row_max, row_lse = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(3))
+        row_arg = torch.empty(n, dtype=torch.int32, device=dev)
+        rc = hip_lib.load().vrwkv_ce_fwd_bf16(n, V, logits.data_ptr(), labels.data_ptr(), row_loss.data_ptr(),
+                                              row_max.data_ptr(), row_lse.data_ptr(), row_arg.data_ptr(), _stream(logits))
+        hip_lib.check(rc, "vrwkv_ce_fwd_bf16")
+        w = ((labels >= 0).float() / (valid.float().unsqueeze(1) * B)).view(n)      # d loss / d row_loss
+        ctx.save_for_backward(logits, labels, w, row_max, row_lse, row_arg)
+        return (row_loss * w).sum().to(logits.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, w, row_max, row_lse, row_arg = ctx.saved_tensors
+        B, T, V = logits.shape
+        dlogits = torch.empty_like(logits)
+        row_w = (w * g.float()).contiguous()
+        rc = hip_lib.load().vrwkv_ce_bwd_bf16(B * T, V, logits.data_ptr(), labels.data_ptr(), row_w.data_ptr(),
+                                              row_max.data_ptr(), row_lse.data_ptr(), row_arg.data_ptr(),
+                                              1e-4 / (B * T), dlogits.data_ptr(), _stream(logits))
+        hip_lib.check(rc, "vrwkv_ce_bwd_bf16")
+        return dlogits, None, None
+
+
+def loss_from_logits(logits, targets, ignore_index=-100):
+    return _FusedCE.apply(logits, targets, ignore_index)
+
+
+def ce_supported(logits):
+    return logits.is_cuda and logits.dtype == torch.bfloat16 and logits.dim() == 3 and logits.shape[-1] % 8 == 0
+
+
 def tmix_forward(m, x, v_first):
     """RWKV_Tmix_x070.forward (src/model.py:163-195) with the glue fused; `m` is the module."""
     B, T, C = x.shape

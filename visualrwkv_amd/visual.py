@@ -131,6 +131,10 @@ class VisualRWKV(nn.Module):
 
     def training_step(self, batch, batch_idx=0):
         logits, targets = self(batch)
+        if getattr(self.args, "fused", False):
+            from . import fused
+            if fused.ce_supported(logits):
+                return fused.loss_from_logits(logits, targets, IGNORE_INDEX)
         return self.loss_from_logits(logits, targets)
 
     @torch.no_grad()
