@@ -6,6 +6,8 @@ travels with the repository to the GPU box.
 """
 from __future__ import annotations
 
+import fcntl
+import hashlib
 import os
 import shutil
 import subprocess
@@ -15,6 +17,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libvisualrwkv_hip.so")
+HASH_PATH = LIB_PATH + ".hash"      # content hash of the sources the library was built from; travels with it
 ARCH = "gfx950"
 
 SOURCES = ["wkv7_capi.hip", "probe.hip", "fused_ops.hip", "tmix_fused.hip", "attention.hip", "wkv7_step.hip", "ln_fused.hip", "wkv6_capi.hip", "loss_fused.hip"]
@@ -31,24 +34,54 @@ def _sources():
     return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
+def _deps():
+    return sorted([os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(REPO_DIR, "include", "visualrwkv_hip.h")])
+
+
+def _digest() -> str:
+    """Content hash of every source the library is built from (mtimes do not survive a copy to another box)."""
+    h = hashlib.sha256()
+    for d in _deps():
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(REPO_DIR, "include", "visualrwkv_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    try:
+        with open(HASH_PATH) as f:
+            return f.read().strip() != _digest()
+    except OSError:
+        # a library without a recorded hash (built by an older version of this file): fall back to mtimes
+        t = os.path.getmtime(LIB_PATH)
+        return any(os.path.getmtime(d) > t for d in _deps())
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source into visualrwkv_amd/libvisualrwkv_hip.so for gfx950."""
+    """Compile every HIP source into visualrwkv_amd/libvisualrwkv_hip.so for gfx950.  Safe to call from several
+    processes at once (one rank per GPU): a file lock lets one of them build, the library appears atomically."""
     if not force and not _stale():
         return LIB_PATH
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I", CSRC, "-I", os.path.join(REPO_DIR, "include"),
-           "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form", *_sources(), "-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():       # another process built it while we waited
+                return LIB_PATH
+            tmp = f"{LIB_PATH}.tmp{os.getpid()}"
+            cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+                   "-I", CSRC, "-I", os.path.join(REPO_DIR, "include"),
+                   "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form", *_sources(), "-o", tmp]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True)
+            os.replace(tmp, LIB_PATH)
+            with open(HASH_PATH, "w") as f:
+                f.write(_digest())
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
