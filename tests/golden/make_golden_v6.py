@@ -112,6 +112,60 @@ def main():
     yy.backward(gyy)
     out["op"] = {"r": r.detach(), "k": k.detach(), "v": v.detach(), "w": w.detach(), "u": u.detach(), "gy": gyy,
                  "y": yy.detach(), "gr": r.grad, "gk": k.grad, "gv": v.grad, "gw": w.grad, "gu": u.grad}
+    # ---- VisualRWKV (v6): CLIP tower stand-in of the same class (random tiny config), grid pooling, embedding assembly,
+    # bidirectional pass, loss -- all through the reference's own code
+    import transformers
+    clip_cfg = transformers.CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2,
+                                             image_size=28, patch_size=7)
+
+    class TinyClip:
+        @staticmethod
+        def from_pretrained(name):
+            torch.manual_seed(5)
+            return transformers.CLIPVisionModel(clip_cfg)
+
+    ref.CLIPVisionModel = TinyClip
+    vargs = SimpleNamespace(n_embd=128, dim_att=128, n_layer=3, head_size_a=64, head_size_divisor=8, dim_ffn=448,
+                            vocab_size=300, dropout=0, grad_cp=0, ctx_len=40, load_model="", vision_tower_name="tiny",
+                            grid_size=2)
+    torch.manual_seed(6)
+    vm = ref.VisualRWKV(vargs)
+    with torch.no_grad():
+        for p in vm.rwkv.parameters():
+            if float(p.abs().sum()) == 0.0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    ids = torch.randint(0, 300, (3, 24), generator=g)
+    ids[0, 5] = ref.IMAGE_TOKEN_INDEX
+    ids[1, 2] = ref.IMAGE_TOKEN_INDEX                  # sample 2 has no image
+    labels = ids.clone()
+    labels[:, :8] = ref.IGNORE_INDEX
+    labels[ids == ref.IMAGE_TOKEN_INDEX] = ref.IGNORE_INDEX
+    images = torch.randn(3, 1, 3, 28, 28, generator=g)
+    out["visual"] = {"args": vars(vargs), "clip": clip_cfg.to_dict(), "state_fp32": {k: v.detach().clone() for k, v in vm.state_dict().items()},
+                     "input_ids": ids, "labels": labels, "images": images, "image_token_index": ref.IMAGE_TOKEN_INDEX}
+    with torch.no_grad():
+        feats = vm.vit(images.view(3, 3, 28, 28)).last_hidden_state
+        pooled = {}
+        for gs in (-1, 0, 1, 2, 4):
+            vm.args.grid_size = gs
+            pooled[gs] = vm.grid_pooling(feats).clone()
+        vm.args.grid_size = 2
+        out["visual"]["clip_features"] = feats
+        out["visual"]["grid_pooling"] = pooled
+    vb = vm.bfloat16()
+    samples = {"input_ids": ids, "labels": labels, "images": images.bfloat16()}
+    x, tg, imf = vb.preparing_embedding(samples)
+    out["visual"]["embeds_bf16"] = x.detach().clone()
+    out["visual"]["targets"] = tg.clone()
+    out["visual"]["img_span"] = (int(vb.img_start), int(vb.img_end))
+    loss = vb.training_step(samples, 0)
+    loss.backward()
+    with torch.no_grad():
+        logits, _ = vb(samples)
+    out["visual"]["logits_bf16"] = logits.detach()
+    out["visual"]["loss"] = float(loss)
+    out["visual"]["grad_proj"] = vb.proj.weight.grad.detach().clone()
+    out["visual"]["grad_head"] = vb.rwkv.head.weight.grad.detach().clone()
     path = os.path.join(HERE, "v6_ref.pt")
     torch.save(out, path)
     print("wrote", path, os.path.getsize(path), "bytes")

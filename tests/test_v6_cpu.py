@@ -127,3 +127,69 @@ def test_wkv6_op_has_no_cpu_path():
     r = torch.zeros(1, 16, 64, dtype=torch.bfloat16)
     with pytest.raises(NotImplementedError):
         wkv6.RUN_CUDA_RWKV6(1, 16, 64, 1, r, r, r, r, torch.zeros(1, 64, dtype=torch.bfloat16))
+
+
+def _oracle_wkv():
+    """An oracle-backed stand-in for RUN_CUDA_RWKV6 (tests may use the oracle; the product op is HIP only)."""
+    class Op(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, r, k, v, w, u):
+            ctx.save_for_backward(r, k, v, w, u)
+            B, T, C = r.shape
+            H = u.shape[0]
+            f = lambda x: x.float().view(B, T, H, C // H)
+            return wkv6_naive(f(r), f(k), f(v), f(w), u.float())[0].reshape(B, T, C).to(r.dtype)
+
+        @staticmethod
+        def backward(ctx, gy):
+            r, k, v, w, u = ctx.saved_tensors
+            B, T, C = r.shape
+            H = u.shape[0]
+            f = lambda x: x.view(B, T, H, C // H)
+            with torch.enable_grad():
+                _, g = wkv6_autograd(f(r), f(k), f(v), f(w), u, f(gy))
+            return tuple(x.reshape(B, T, C).to(r.dtype) for x in g[:4]) + (g[4].to(u.dtype),)
+    return lambda B, T, C, H, r, k, v, w, u: Op.apply(r, k, v, w, u)
+
+
+def _visual(gold):
+    import transformers
+    from visualrwkv_amd import visual6
+    vis = gold["visual"]
+    args = SimpleNamespace(**vis["args"])
+    clip = transformers.CLIPVisionModel(transformers.CLIPVisionConfig(**{k: v for k, v in vis["clip"].items()
+                                                                         if k in ("hidden_size", "intermediate_size", "num_hidden_layers",
+                                                                                  "num_attention_heads", "image_size", "patch_size")}))
+    m = visual6.VisualRWKV6(args, clip, clip.config.hidden_size)
+    assert vis["image_token_index"] == visual6.IMAGE_TOKEN_INDEX
+    return m, vis
+
+
+def test_visualrwkv6_state_dict_and_grid_pooling(gold):
+    m, vis = _visual(gold)
+    assert list(m.state_dict().keys()) == list(vis["state_fp32"].keys())
+    m.load_state_dict(vis["state_fp32"])
+    for gs, ref in vis["grid_pooling"].items():
+        m.args.grid_size = gs
+        assert torch.equal(m.grid_pooling(vis["clip_features"]), ref), gs
+
+
+def test_visualrwkv6_embedding_assembly_and_training_step(gold):
+    """preparing_embedding (left-padded first text part | image span | rest), the bidirectional pass and the loss,
+    against the reference's bf16 run."""
+    m, vis = _visual(gold)
+    m.load_state_dict(vis["state_fp32"])
+    m = m.bfloat16()
+    samples = {"input_ids": vis["input_ids"], "labels": vis["labels"], "images": vis["images"].bfloat16()}
+    x, tg, _ = m.preparing_embedding(samples)
+    assert torch.equal(tg, vis["targets"]) and (m.img_start, m.img_end) == tuple(vis["img_span"])
+    assert x.shape == vis["embeds_bf16"].shape and rel_rms(x.float(), vis["embeds_bf16"].float()) < 1e-2
+    wkv = _oracle_wkv()
+    loss = m.training_step(samples, 0, wkv)
+    loss.backward()
+    assert abs(float(loss) - vis["loss"]) < 2e-2 * abs(vis["loss"])
+    with torch.no_grad():
+        logits, _ = m(samples, wkv)
+    assert rel_rms(logits.float(), vis["logits_bf16"].float()) < 2e-2
+    assert rel_rms(m.proj.weight.grad.float(), vis["grad_proj"].float()) < 5e-2
+    assert rel_rms(m.rwkv.head.weight.grad.float(), vis["grad_head"].float()) < 5e-2

@@ -104,3 +104,54 @@ class RWKV_CMix_x060(nn.Module):
         xr = x + xx * self.time_maa_r
         k = torch.relu(self.key(xk)) ** 2
         return torch.sigmoid(self.receptance(xr)) * self.value(k)
+
+
+class Block(nn.Module):
+    """Pre-LN residual block of RWKV-6 (model.py:233-258); block 0 also owns ln0."""
+
+    def __init__(self, args, layer_id):
+        super().__init__()
+        self.args = args
+        self.layer_id = layer_id
+        self.ln1 = nn.LayerNorm(args.n_embd)
+        self.ln2 = nn.LayerNorm(args.n_embd)
+        if layer_id == 0:
+            self.ln0 = nn.LayerNorm(args.n_embd)
+        self.att = RWKV_Tmix_x060(args, layer_id)
+        self.ffn = RWKV_CMix_x060(args, layer_id)
+        if args.dropout > 0:
+            self.drop0 = nn.Dropout(p=args.dropout)
+            self.drop1 = nn.Dropout(p=args.dropout)
+
+    def forward(self, x, wkv=None):
+        if self.layer_id == 0:
+            x = self.ln0(x)
+        x = x + self.att(self.ln1(x), wkv)
+        x = x + self.ffn(self.ln2(x))
+        return x
+
+
+class RWKV(nn.Module):
+    """Embedding -> n_layer Blocks -> ln_out -> head (model.py:277-325); same state-dict keys as the reference."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.emb = nn.Embedding(args.vocab_size, args.n_embd)
+        self.blocks = nn.ModuleList([Block(args, i) for i in range(args.n_layer)])
+        self.ln_out = nn.LayerNorm(args.n_embd)
+        self.head = nn.Linear(args.n_embd, args.vocab_size, bias=False)
+        if args.dropout > 0:
+            self.drop0 = nn.Dropout(p=args.dropout)
+
+    def forward(self, x, wkv=None):
+        args = self.args
+        if args.dropout > 0:
+            x = self.drop0(x)
+        for block in self.blocks:
+            if args.grad_cp == 1 and torch.is_grad_enabled():
+                from torch.utils.checkpoint import checkpoint
+                x = checkpoint(block, x, wkv, use_reentrant=False)
+            else:
+                x = block(x, wkv)
+        return self.head(self.ln_out(x))
