@@ -65,19 +65,23 @@ def main():
         engine.step(2e-5)
         return loss
 
+    losses = []
     for _ in range(a.warmup):
         loss = step()
+        losses.append(round(float(loss.detach()), 3))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
+        losses.append(loss.detach())
     torch.cuda.synchronize()
+    losses = [float(x) if torch.is_tensor(x) else x for x in losses]
     dt = (time.perf_counter() - t0) / a.steps
     T = T_text + 577
     n_par = sum(p.numel() for p in model.rwkv.parameters())
     print(json.dumps({"config": "cfg4: VisualRWKV-6 %dL C%d + CLIP ViT-L/14-336" % (a.layers, C), "lm_params_B": round(n_par / 1e9, 2),
                       "micro_bsz": B, "seq_len": T, "tokens_per_s": round(B * T / dt), "ms_per_step": round(dt * 1e3, 1),
-                      "loss": float(loss), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1), "grad_cp": a.grad_cp}))
+                      "losses": [round(x, 3) for x in losses], "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1), "grad_cp": a.grad_cp}))
 
 
 if __name__ == "__main__":
