@@ -95,7 +95,9 @@ int vrwkv_wkv7_step_bf16(int B, int H, const void* w, const void* q, const void*
 /* Launch-shape override for benchmarking/tests: variant < 0 restores the automatic choice.
  * forward variants: 0/1/2 = sequential VALU kernel with 1/2/4 waves per head, 3 = chunked bf16x3 MFMA kernel
  * (4 waves, phases back to back), 4..7 = chunked MFMA kernel with producer/consumer wave specialisation
- * (4: 16-byte stores + producer priority, 5: scalar stores + priority [default], 6/7: same without priority). */
+ * (4: 16-byte stores + producer priority, 5: scalar stores + priority [default], 6/7: same without priority,
+ * 8: 5 + two chunks of input prefetch, 9: 5 + DPP suffix scan, 10: both, 11: 5 + ds_read_b64_tr_b16 operand reads
+ * instead of transposed LDS copies; 8..11 measured within +-2 % of 5 on MI355X). */
 int vrwkv_wkv7_set_forward_variant(int variant);
 /* backward variants: 0 = sequential VALU kernel, 1 = chunked bf16x3 MFMA kernel (4 waves, phases back to back),
  * 2..5 = chunked MFMA kernel with producer/consumer wave specialisation: 2 workgroup barriers + f32 doubling for T,

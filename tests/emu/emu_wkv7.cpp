@@ -21,7 +21,8 @@ int emu_wkv7_forward(int B, int T, int H, const void* w, const void* q, const vo
     else if (variant == 3) emu::launch(grid, dim3(256), [&] { wkv7c::fwd_kernel_t<false>(p); });
     else if (variant == 4) emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false>(p); });                       // wide stores
     else if (variant == 5) emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1>(p); });             // narrow stores
-    else emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1, 2, true>(p); });                      // + prefetch 2, DPP suffix
+    else if (variant == 10) emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1, 2, true>(p); });  // + prefetch 2, DPP suffix
+    else emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1, 1, false, true>(p); });              // transpose reads
     return 0;
 }
 

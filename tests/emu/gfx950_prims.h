@@ -202,6 +202,20 @@ DEVFN unsigned long long clock64_() { return 0; }
 DEVFN void block_sync() { emu::block_barrier(); }
 DEVFN void block_sync_lds() { emu::block_barrier(); }
 DEVFN void wave_lds_fence() { emu::wave_barrier(); }
+DEVFN uint2 lds_read_tr16(const uint16_t* p) {
+    int me = emu::flat_tid(), wb = emu::wave_base(), l = me & 63;
+    uint16_t* s = (uint16_t*)emu::slot(me);
+    for (int e = 0; e < 4; ++e) s[e] = p[e];
+    emu::wave_barrier();
+    uint16_t o[4];
+    const int grp = l & 48, i = l & 15;
+    for (int e = 0; e < 4; ++e) o[e] = ((uint16_t*)emu::slot(wb + grp + 4 * e + (i >> 2)))[i & 3];
+    emu::wave_barrier();
+    uint2 r;
+    r.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+    r.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+    return r;
+}
 DEVFN void lds_flag_add(unsigned* cnt) {
     emu::wave_barrier();
     if ((emu::flat_tid() & 63) == 0) *(volatile unsigned*)cnt += 1;

@@ -56,3 +56,14 @@ def test_mfma_issue_rate_report(hip_lib):
     print("MFMA_RATE cycles/instr: x32 chains1 %.1f chains4 %.1f chains8 %.1f | x16 chains1 %.1f chains4 %.1f chains8 %.1f"
           % (r[0], r[1], r[5], r[2], r[3], r[4]))
     assert all(x > 0 for x in r[:6])
+
+
+def test_lds_transpose_read(hip_lib):
+    """ds_read_b64_tr_b16 as documented in gfx950_prims.h (and modelled by the emulator): lane l of a 16-lane group
+    pointing at row l>>2, columns 4(l&3).. of a 4x16 block receives column l of that block."""
+    img = torch.arange(64 * 80, dtype=torch.float32).view(64, 80)
+    d = _probe(hip_lib, 7, img.cuda(), None, (256,)).cpu().view(64, 4)
+    for l in range(64):
+        g, i = l >> 4, l & 15
+        expect = [float(img[4 * g + e, i]) for e in range(4)]
+        assert d[l].tolist() == expect, (l, d[l].tolist(), expect)

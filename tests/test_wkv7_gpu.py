@@ -44,7 +44,7 @@ def _capi_backward(lib, w, q, k, v, z, a, dy, s, sa):
     return outs
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 8, 9, 10, -1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 8, 9, 10, 11, -1])
 @pytest.mark.parametrize("B,T,H", [(1, 16, 1), (2, 64, 3), (1, 384, 12), (3, 208, 5)])
 def test_forward_parity(hip_lib, dev, B, T, H, variant):
     w, q, k, v, z, a, _ = make_inputs(B, T, H, seed=B * 1000 + T + H)

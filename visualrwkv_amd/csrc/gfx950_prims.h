@@ -151,6 +151,19 @@ template <int P> DEVFN void wave_priority() { __builtin_amdgcn_s_setprio(P); }
 // shader clock (s_memtime), for in-kernel phase timing
 DEVFN unsigned long long clock64_() { return __builtin_readcyclecounter(); }
 
+// ---------------------------------------------------------------- LDS transpose read (gfx950)
+// ds_read_b64_tr_b16: every lane supplies the LDS address of 4 consecutive 16-bit elements; inside each group of 16
+// lanes the 16 x 4 elements are transposed: lane i receives element (i & 3) of lanes 4e + (i >> 2), e = 0..3.
+// With lane i pointing at row (i >> 2), columns 4 (i & 3) .. +3 of a row-major [4][16] block (any row stride), lane i
+// gets column i of the block, rows 0..3 -- an MFMA operand whose k index runs along the rows of a row-major image,
+// with no transposed copy in LDS.  Checked on hardware by tests/test_probe_gpu.py.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+DEVFN uint2 lds_read_tr16(const uint16_t* p) {
+    typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(uint32_t)(uintptr_t)p);
+    return __builtin_bit_cast(uint2, v);
+}
+
 // ---------------------------------------------------------------- sync
 DEVFN void block_sync() { __syncthreads(); }
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for

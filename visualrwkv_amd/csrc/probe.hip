@@ -104,6 +104,18 @@ __global__ void probe_mfma_rate(float* D) {
     if (l == 0) { D[0] = r0; D[1] = r1; D[2] = r2; D[3] = r3; D[4] = r4; D[5] = r5; }
 }
 
+// ds_read_b64_tr_b16: in = 64 x 80 floats (integers < 32768) copied to a [64][80] u16 LDS image; lane l points at row
+// 4 (l>>4) + ((l&15)>>2), columns 4 (l&3)..+3; out[l*4 + e] = what the lane received.
+__global__ void probe_tr16(const float* in, float* out) {
+    __shared__ __attribute__((aligned(16))) uint16_t img[64][80];
+    const int l = threadIdx.x;
+    for (int i = l; i < 64 * 80; i += 64) img[i / 80][i % 80] = (uint16_t)in[i];
+    block_sync();
+    const uint2 v = lds_read_tr16(&img[4 * (l >> 4) + ((l & 15) >> 2)][4 * (l & 3)]);
+    out[l * 4 + 0] = (float)(v.x & 0xffff); out[l * 4 + 1] = (float)(v.x >> 16);
+    out[l * 4 + 2] = (float)(v.y & 0xffff); out[l * 4 + 3] = (float)(v.y >> 16);
+}
+
 }  // namespace
 
 extern "C" int vrwkv_debug_probe(int which, const float* a, const float* b, float* d, void* stream) {
@@ -117,6 +129,7 @@ extern "C" int vrwkv_debug_probe(int which, const float* a, const float* b, floa
         case 4: hipLaunchKernelGGL(probe_lanes, dim3(1), dim3(64), 0, st, a, d); break;
         case 5: hipLaunchKernelGGL(probe_16x16x16_bf16, dim3(1), dim3(64), 0, st, a, b, d); break;
         case 6: hipLaunchKernelGGL(probe_mfma_rate, dim3(1), dim3(64), 0, st, d); break;
+        case 7: hipLaunchKernelGGL(probe_tr16, dim3(1), dim3(64), 0, st, a, d); break;
         default: return VRWKV_EINVAL;
     }
     hipError_t e = hipGetLastError();

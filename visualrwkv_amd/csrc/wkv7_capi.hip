@@ -45,7 +45,7 @@ const char* vrwkv_strerror(int code) {
 }
 
 int vrwkv_wkv7_set_forward_variant(int variant) {
-    if (variant > 10) return VRWKV_EINVAL;
+    if (variant > 11) return VRWKV_EINVAL;
     g_fwd_variant = variant;
     return VRWKV_OK;
 }
@@ -91,7 +91,8 @@ int vrwkv_wkv7_forward_bf16(int B, int T, int H, const void* w, const void* q, c
         else if (variant == 7) e = launch(&wkv7c::fwd_kernel_v3<false, false, 0>);
         else if (variant == 8) e = launch(&wkv7c::fwd_kernel_v3<false, false, 1, 2, false>);     // 5 + two chunks of prefetch
         else if (variant == 9) e = launch(&wkv7c::fwd_kernel_v3<false, false, 1, 1, true>);      // 5 + DPP suffix scan
-        else e = launch(&wkv7c::fwd_kernel_v3<false, false, 1, 2, true>);                        // 5 + both
+        else if (variant == 10) e = launch(&wkv7c::fwd_kernel_v3<false, false, 1, 2, true>);     // 5 + both
+        else e = launch(&wkv7c::fwd_kernel_v3<false, false, 1, 1, false, true>);                 // 5 + transpose reads (no transposed LDS copies)
         if (e) return e;
     }
     return finish_launch();

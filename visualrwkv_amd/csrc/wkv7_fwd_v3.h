@@ -24,11 +24,21 @@
 namespace wkv7c {
 
 constexpr int SF = 20;   // fp32 [t][s] image row stride (80 B)
+constexpr int TS = 80;   // [t][j] row stride (160 B) of images read with ds_read_b64_tr_b16: the 8 rows x 32 B a half-wave
+                         // touches fall into 8 distinct 32-byte bank groups
 
 struct BufF {
     uint16_t opnd[8][L][TJ];      // Zt Qt Ah Kh (hi,lo)  [t][j]
-    uint16_t trn[4][N][JT];       // Ab Kb (hi,lo)        [j][t]
-    uint16_t vt[N][JT];           // v                    [i][t]
+    union {                       // the operands whose MFMA k index is the token:
+        struct {                  //   transposed copies built by the producers with 2-byte LDS stores ...
+            uint16_t trn[4][N][JT];       // Ab Kb (hi,lo)        [j][t]
+            uint16_t vt[N][JT];           // v                    [i][t]
+        };
+        struct {                  //   ... or (TRD) natural row-major images read with ds_read_b64_tr_b16
+            uint16_t abn[4][L][TS];       // Ab_hi Ab_lo Kb_hi Kb_lo  [t][j]
+            uint16_t vn[L][TS];           // v                        [t][i]
+        };
+    };
     uint16_t scb[2][2][L][SS];    // 0 M_zk  1 M_qk ; [hi,lo][t][s]
     float scf[2][L][SF];          // 0 M_qa  1 T    ; fp32 [t][s]
     float cl[N];                  // c_L[j]
@@ -64,7 +74,7 @@ DEVFN f32x4 mm_f32_image(f32x4 acc, const float (*M)[SF], int c16, int g, f32x4 
     return acc;
 }
 
-template <bool SFX>
+template <bool SFX, bool TRD = false>
 DEVFN void prep_v3(BufF& B, const RawChunk& rc, int pw, int lane) {
     const int t = lane & 15, g = lane >> 4, j0 = 16 * pw + 4 * g;
     float wr[4], q[4], k[4], z[4], a[4];
@@ -92,18 +102,24 @@ DEVFN void prep_v3(BufF& B, const RawChunk& rc, int pw, int lane) {
     split4(qt, h, l); st8(&B.opnd[2][t][j0], h); st8(&B.opnd[3][t][j0], l);
     split4(ah, h, l); st8(&B.opnd[4][t][j0], h); st8(&B.opnd[5][t][j0], l);
     split4(kh, h, l); st8(&B.opnd[6][t][j0], h); st8(&B.opnd[7][t][j0], l);
-    split4(ab, h, l);
-    B.trn[0][j0 + 0][t] = (uint16_t)h.x; B.trn[0][j0 + 1][t] = (uint16_t)(h.x >> 16);
-    B.trn[0][j0 + 2][t] = (uint16_t)h.y; B.trn[0][j0 + 3][t] = (uint16_t)(h.y >> 16);
-    B.trn[1][j0 + 0][t] = (uint16_t)l.x; B.trn[1][j0 + 1][t] = (uint16_t)(l.x >> 16);
-    B.trn[1][j0 + 2][t] = (uint16_t)l.y; B.trn[1][j0 + 3][t] = (uint16_t)(l.y >> 16);
-    split4(kb, h, l);
-    B.trn[2][j0 + 0][t] = (uint16_t)h.x; B.trn[2][j0 + 1][t] = (uint16_t)(h.x >> 16);
-    B.trn[2][j0 + 2][t] = (uint16_t)h.y; B.trn[2][j0 + 3][t] = (uint16_t)(h.y >> 16);
-    B.trn[3][j0 + 0][t] = (uint16_t)l.x; B.trn[3][j0 + 1][t] = (uint16_t)(l.x >> 16);
-    B.trn[3][j0 + 2][t] = (uint16_t)l.y; B.trn[3][j0 + 3][t] = (uint16_t)(l.y >> 16);
-    B.vt[j0 + 0][t] = (uint16_t)rc.v.x; B.vt[j0 + 1][t] = (uint16_t)(rc.v.x >> 16);
-    B.vt[j0 + 2][t] = (uint16_t)rc.v.y; B.vt[j0 + 3][t] = (uint16_t)(rc.v.y >> 16);
+    if (TRD) {
+        split4(ab, h, l); st8(&B.abn[0][t][j0], h); st8(&B.abn[1][t][j0], l);
+        split4(kb, h, l); st8(&B.abn[2][t][j0], h); st8(&B.abn[3][t][j0], l);
+        st8(&B.vn[t][j0], rc.v);
+    } else {
+        split4(ab, h, l);
+        B.trn[0][j0 + 0][t] = (uint16_t)h.x; B.trn[0][j0 + 1][t] = (uint16_t)(h.x >> 16);
+        B.trn[0][j0 + 2][t] = (uint16_t)h.y; B.trn[0][j0 + 3][t] = (uint16_t)(h.y >> 16);
+        B.trn[1][j0 + 0][t] = (uint16_t)l.x; B.trn[1][j0 + 1][t] = (uint16_t)(l.x >> 16);
+        B.trn[1][j0 + 2][t] = (uint16_t)l.y; B.trn[1][j0 + 3][t] = (uint16_t)(l.y >> 16);
+        split4(kb, h, l);
+        B.trn[2][j0 + 0][t] = (uint16_t)h.x; B.trn[2][j0 + 1][t] = (uint16_t)(h.x >> 16);
+        B.trn[2][j0 + 2][t] = (uint16_t)h.y; B.trn[2][j0 + 3][t] = (uint16_t)(h.y >> 16);
+        B.trn[3][j0 + 0][t] = (uint16_t)l.x; B.trn[3][j0 + 1][t] = (uint16_t)(l.x >> 16);
+        B.trn[3][j0 + 2][t] = (uint16_t)l.y; B.trn[3][j0 + 3][t] = (uint16_t)(l.y >> 16);
+        B.vt[j0 + 0][t] = (uint16_t)rc.v.x; B.vt[j0 + 1][t] = (uint16_t)(rc.v.x >> 16);
+        B.vt[j0 + 2][t] = (uint16_t)rc.v.y; B.vt[j0 + 3][t] = (uint16_t)(rc.v.y >> 16);
+}
     if (t == 15) *reinterpret_cast<float4*>(&B.cl[j0]) = make_float4(cend[0], cend[1], cend[2], cend[3]);
 }
 
@@ -166,7 +182,7 @@ DEVFN void scores_v3(BufF& B, int pw, int lane) {
 
 // PF: chunks of input prefetch held in registers by the producers (HBM latency under load exceeds one chunk time);
 // SFX: decay suffix by DPP scan instead of ds_bpermute.
-template <bool PROF, bool WIDE = true, int PRIO = 1, int PF = 1, bool SFX = false>
+template <bool PROF, bool WIDE = true, int PRIO = 1, int PF = 1, bool SFX = false, bool TRD = false>
 __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
     LdsF& lds = *reinterpret_cast<LdsF*>(dyn_lds());
     const int T = p.T, H = p.H;
@@ -202,7 +218,7 @@ __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
                     rc = rc2;
                     if (c + 2 < nchunk) fetch(rc2, c + 2);
                 } else if (c + 1 < nchunk) fetch(rc, c + 1);
-                prep_v3<SFX>(lds.b[c & 1], cur, pw, lane);
+                prep_v3<SFX, TRD>(lds.b[c & 1], cur, pw, lane);
                 lds_flag_add(&lds.prep_done);
             }
             WKV_STAMP(0)
@@ -243,7 +259,9 @@ __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
         for (int jb = 0; jb < 4; ++jb) split4(S[jb], sh[jb], sl[jb]);
         const bf16x8 bsh[2] = {mk8(sh[0], sh[1]), mk8(sh[2], sh[3])};
         const bf16x8 bsl[2] = {mk8(sl[0], sl[1]), mk8(sl[2], sl[3])};
-        const uint2 vv = ld8(&B.vt[16 * wave + c16][4 * g]);
+        // lane (c16, g) needs v[t = 4g+e][i = 16w + c16]: column c16 of the 4 x 16 block at rows 4g.., columns 16w..
+        const uint2 vv = TRD ? lds_read_tr16(&B.vn[4 * g + (c16 >> 2)][16 * wave + 4 * (c16 & 3)])
+                             : ld8(&B.vt[16 * wave + c16][4 * g]);
         const bf16x8 bvv = mk8(vv, vv);
 
         // R = M_zk V + Zt S0^T  (three independent accumulator chains)
@@ -305,8 +323,15 @@ __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
             f32x4 acc = S[jb];
             acc[0] *= cl.x; acc[1] *= cl.y; acc[2] *= cl.z; acc[3] *= cl.w;
             const int j = 16 * jb + c16;
-            const bf16x8 ah = mk8(ld8(&B.trn[0][j][4 * g]), ld8(&B.trn[2][j][4 * g]));
-            const bf16x8 al = mk8(ld8(&B.trn[1][j][4 * g]), ld8(&B.trn[3][j][4 * g]));
+            bf16x8 ah, al;
+            if (TRD) {
+                const int tr = 4 * g + (c16 >> 2), tc = 16 * jb + 4 * (c16 & 3);
+                ah = mk8(lds_read_tr16(&B.abn[0][tr][tc]), lds_read_tr16(&B.abn[2][tr][tc]));
+                al = mk8(lds_read_tr16(&B.abn[1][tr][tc]), lds_read_tr16(&B.abn[3][tr][tc]));
+            } else {
+                ah = mk8(ld8(&B.trn[0][j][4 * g]), ld8(&B.trn[2][j][4 * g]));
+                al = mk8(ld8(&B.trn[1][j][4 * g]), ld8(&B.trn[3][j][4 * g]));
+            }
             acc = mfma_16x16x32_bf16(ah, b1, acc);
             acc = mfma_16x16x32_bf16(ah, b2, acc);
             acc = mfma_16x16x32_bf16(al, b1, acc);
