@@ -165,6 +165,18 @@ DEVFN void bwd_dscores(LdsB3& lds, const BufB& B, int pw, int lane) {
     }
 }
 
+// acc += M B for a 16x16 score-type A (hi/lo images) and a register B given as (hi, lo): with A = [M_h | M_l] (one
+// ds_read2_b64, no register assembly), B1 = [b_h ; b_h] gives M_h b_h + M_l b_h and B2 = [b_l ; 0] adds M_h b_l.
+// The two B operands are built once per (hi, lo) pair and shared by the products that use it (mm_small of
+// wkv7_chunked_bwd.h duplicates M_h instead: 7 register moves per product).
+struct BPair { bf16x8 dup, lo0; };
+DEVFN BPair make_bpair(uint2 bh, uint2 bl) { return BPair{mk8(bh, bh), mk8(bl.x, bl.y, 0u, 0u)}; }
+DEVFN f32x4 mm_small2(f32x4 acc, const uint16_t (*Mh)[SS], const uint16_t (*Ml)[SS], int row, int g, const BPair& b) {
+    const bf16x8 a = mk8(ld8(&Mh[row][4 * g]), ld8(&Ml[row][4 * g]));
+    acc = mfma_16x16x32_bf16(a, b.dup, acc);
+    return mfma_16x16x32_bf16(a, b.lo0, acc);
+}
+
 // ------------------------------------------------------------------------------------------ kernel
 // MODE bit 0: hand-off counters instead of workgroup barriers; bit 1: T doubling on the bf16 matrix core (bf16x3)
 // instead of the f32 one.  Both are kept selectable for same-process A/B timing (benchmarks/wkv7_micro.py).
@@ -301,11 +313,11 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
             dSA = mm_perm<true>(dSA, B.ab[0], B.ab[1], c16, g, bh, bl);                             // Ab dS^T
             uint2 xh, xl;
             split4(dSA, xh, xl);
-            const f32x4 dR = mm_small(zero4(), B.sc[3][0], B.sc[3][1], c16, g, xh, xl);             // T^T dSA
+            const f32x4 dR = mm_small2(zero4(), B.sc[3][0], B.sc[3][1], c16, g, make_bpair(xh, xl));             // T^T dSA
             split4(dR, rh, rl);
             f32x4 dV = mm_small_exact(zero4(), B.sc[1][0], B.sc[1][1], c16, g, dy);                 // M_qk^T dY
             dV = mm_perm<true>(dV, B.ab[2], B.ab[3], c16, g, bh, bl);                               // Kb dS^T
-            dV = mm_small(dV, B.sc[2][0], B.sc[2][1], c16, g, rh, rl);                              // M_zk^T dR
+            dV = mm_small2(dV, B.sc[2][0], B.sc[2][1], c16, g, make_bpair(rh, rl));                              // M_zk^T dR
             st_b16x4_col(lds.dr[0], 4 * g, 16 * wave + c16, rh);
             st_b16x4_col(lds.dr[1], 4 * g, 16 * wave + c16, rl);
             st8(&lds.drT[0][16 * wave + c16][4 * g], rh);
@@ -395,14 +407,15 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
         {
             const uint2 ahh = ld8(&B.trn[4][j][4 * g]), ahl = ld8(&B.trn[5][j][4 * g]);
             const uint2 khh = ld8(&B.trn[6][j][4 * g]), khl = ld8(&B.trn[7][j][4 * g]);
-            dZt = mm_small(dZt, lds.dsc[0][0], lds.dsc[0][1], c16, g, ahh, ahl);                    // dM_za Ah
-            dZt = mm_small(dZt, lds.dsc[2][0], lds.dsc[2][1], c16, g, khh, khl);                    // dM_zk Kh
-            dQt = mm_small(dQt, lds.dsc[4][0], lds.dsc[4][1], c16, g, ahh, ahl);                    // dM_qa Ah
-            dQt = mm_small(dQt, lds.dsc[6][0], lds.dsc[6][1], c16, g, khh, khl);                    // dM_qk Kh
-            dAh = mm_small(dAh, lds.dsc[1][0], lds.dsc[1][1], c16, g, zth, ztl);                    // dM_za^T Zt
-            dAh = mm_small(dAh, lds.dsc[5][0], lds.dsc[5][1], c16, g, qth, qtl);                    // dM_qa^T Qt
-            dKh = mm_small(dKh, lds.dsc[3][0], lds.dsc[3][1], c16, g, zth, ztl);                    // dM_zk^T Zt
-            dKh = mm_small(dKh, lds.dsc[7][0], lds.dsc[7][1], c16, g, qth, qtl);                    // dM_qk^T Qt
+            const BPair bpa = make_bpair(ahh, ahl), bpk = make_bpair(khh, khl), bpz = make_bpair(zth, ztl), bpq = make_bpair(qth, qtl);
+            dZt = mm_small2(dZt, lds.dsc[0][0], lds.dsc[0][1], c16, g, bpa);                         // dM_za Ah
+            dZt = mm_small2(dZt, lds.dsc[2][0], lds.dsc[2][1], c16, g, bpk);                         // dM_zk Kh
+            dQt = mm_small2(dQt, lds.dsc[4][0], lds.dsc[4][1], c16, g, bpa);                         // dM_qa Ah
+            dQt = mm_small2(dQt, lds.dsc[6][0], lds.dsc[6][1], c16, g, bpk);                         // dM_qk Kh
+            dAh = mm_small2(dAh, lds.dsc[1][0], lds.dsc[1][1], c16, g, bpz);                         // dM_za^T Zt
+            dAh = mm_small2(dAh, lds.dsc[5][0], lds.dsc[5][1], c16, g, bpq);                         // dM_qa^T Qt
+            dKh = mm_small2(dKh, lds.dsc[3][0], lds.dsc[3][1], c16, g, bpz);                         // dM_zk^T Zt
+            dKh = mm_small2(dKh, lds.dsc[7][0], lds.dsc[7][1], c16, g, bpq);                         // dM_qk^T Qt
             // decay-gradient integrand G[t][j] = dq q - da a - dk k + (dz z)[t+1]   (t = 4g + r, C layout)
             float zh[4], zl[4], qh[4], ql[4], ah[4], al[4], kh[4], kl[4], pz[4];
             unpack4(zth, zh); unpack4(ztl, zl); unpack4(qth, qh); unpack4(qtl, ql);
