@@ -58,16 +58,17 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("VRWKV_HIP_LIB", LIB_PATH)      # benchmarking aid: a library built with other compiler flags
+    if not os.path.exists(path):
         raise HipLibraryError(
-            f"{LIB_PATH} is missing. Build it with `python -m visualrwkv_amd.build` "
+            f"{path} is missing. Build it with `python -m visualrwkv_amd.build` "
             "(hipcc --offload-arch=gfx950); there is no CPU or PyTorch fallback for the WKV7 operator.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in PROTOTYPES.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
-            raise HipLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+            raise HipLibraryError(f"{path} does not export {name}; rebuild it") from e
         fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib
