@@ -9,8 +9,9 @@ from visualrwkv_amd import hip_lib
 FWD = ["c_top", "c_main1", "c_waitA", "c_store_y_sa", "c_supdate_store_s", "c_waitB", "-", "-", "p_prep", "p_waitA", "p_scores", "p_waitB"]
 BWD = ["c_isplit", "c_waitX", "c_jsplit", "c_waitY", "c_tail_waitZ", "c_start", "-", "-", "p_start", "p_prepA_waitX", "p_prepB", "p_flagwait", "p_dM_waitY", "p_scores_waitZ"]
 
-def run(B=8, T=2624, H=32):
+def run(B=8, T=2624, H=32, bwd_variant=-1):
     lib = hip_lib.load()
+    lib.vrwkv_wkv7_set_backward_variant(bwd_variant)
     dev = "cuda:0"
     w, q, k, v, z, a, dy = synth_inputs(B, T, H, dev)
     y = torch.empty_like(v); s = torch.empty(B, H, T // 16, 64, 64, device=dev); sa = torch.empty(B, T, H, 64, device=dev)
@@ -31,4 +32,5 @@ def run(B=8, T=2624, H=32):
 
 if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-    print(json.dumps(run(B=B)))
+    bv = int(sys.argv[2]) if len(sys.argv) > 2 else -1
+    print(json.dumps(run(B=B, bwd_variant=bv)))

@@ -101,7 +101,8 @@ int vrwkv_wkv7_step_bf16(int B, int H, const void* w, const void* q, const void*
 int vrwkv_wkv7_set_forward_variant(int variant);
 /* backward variants: 0 = sequential VALU kernel, 1 = chunked bf16x3 MFMA kernel (4 waves, phases back to back),
  * 2..5 = chunked MFMA kernel with producer/consumer wave specialisation: 2 workgroup barriers + f32 doubling for T,
- * 3 LDS hand-off counters instead of barriers, 4 barriers + bf16x3 doubling [default], 5 counters + bf16x3. */
+ * 3 LDS hand-off counters instead of barriers, 4 barriers + bf16x3 doubling [default], 5 counters + bf16x3,
+ * 6 = 12-wave kernel with the consumer work split by role (wkv7_bwd_v4.h; 12 % slower: the SIMDs are issue-bound). */
 int vrwkv_wkv7_set_backward_variant(int variant);
 
 /* ---- Fused element-wise glue of RWKV_Tmix_x070 / RWKV_CMix_x070 (VisualRWKV-v7/v7.00/src/model.py), forward and

@@ -6,6 +6,7 @@
 #include <wkv7_chunked_bwd.h>
 #include <wkv7_fwd_v3.h>
 #include <wkv7_bwd_v3.h>
+#include <wkv7_bwd_v4.h>
 #include <wkv6_chunked.h>
 
 extern "C" {
@@ -50,7 +51,8 @@ int emu_wkv7_backward_chunked(int B, int T, int H, const void* w, const void* q,
     else if (mode == 0) emu::launch(grid, dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 0>(p); });
     else if (mode == 1) emu::launch(grid, dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 1>(p); });
     else if (mode == 2) emu::launch(grid, dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 2>(p); });
-    else emu::launch(grid, dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 3>(p); });
+    else if (mode == 3) emu::launch(grid, dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 3>(p); });
+    else emu::launch(grid, dim3(768), [&] { wkv7c::bwd_kernel_v4<false>(p); });
     return (int)sizeof(wkv7c::LdsB3);
 }
 

@@ -37,7 +37,7 @@ def test_backward(emu_lib):
         assert rel_rms(o.float(), r.float()) < 1e-3, name
 
 
-@pytest.mark.parametrize("mode", [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [-1, 0, 1, 2, 3, 4])
 def test_backward_chunked(emu_lib, mode):
     """Chunked MFMA backward kernels run lane-exactly on the host: the 4-wave kernel (-1) and the 8-wave
     producer/consumer kernel with workgroup barriers or LDS hand-off counters (bit 0) and f32 / bf16x3 doubling (bit 1)."""

@@ -8,6 +8,7 @@
 #include <wkv7_chunked_bwd.h>
 #include <wkv7_fwd_v3.h>
 #include <wkv7_bwd_v3.h>
+#include <wkv7_bwd_v4.h>
 
 namespace {
 
@@ -51,7 +52,7 @@ int vrwkv_wkv7_set_forward_variant(int variant) {
 }
 
 int vrwkv_wkv7_set_backward_variant(int variant) {
-    if (variant > 5) return VRWKV_EINVAL;
+    if (variant > 6) return VRWKV_EINVAL;
     g_bwd_variant = variant;
     return VRWKV_OK;
 }
@@ -132,6 +133,15 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H, const void* w, const void* q, 
         int e = mode == 0 ? launch(&wkv7c::bwd_kernel_v3<false, 0>, at0) : mode == 1 ? launch(&wkv7c::bwd_kernel_v3<false, 1>, at1)
               : mode == 2 ? launch(&wkv7c::bwd_kernel_v3<false, 2>, at2) : launch(&wkv7c::bwd_kernel_v3<false, 3>, at3);
         if (e) return e;
+    } else if (g_bwd_variant == 6) {      // 12 waves: I / J consumer roles + producers (wkv7_bwd_v4.h)
+        static bool attr4_set = false;
+        if (!attr4_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::bwd_kernel_v4<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsB3));
+            if (e != hipSuccess) return (int)e;
+            attr4_set = true;
+        }
+        hipLaunchKernelGGL(wkv7c::bwd_kernel_v4<false>, grid, dim3(768), sizeof(wkv7c::LdsB3), st, p);
     } else {
         static bool attr_set = false;     // > 64 KB of LDS needs the opt-in once per process
         if (!attr_set) {
@@ -176,6 +186,11 @@ int vrwkv_wkv7_profile_bf16(int backward, int B, int T, int H, const void* w, co
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsB));
             if (e != hipSuccess) return (int)e;
             hipLaunchKernelGGL(wkv7c::bwd_kernel_t<true>, grid, dim3(256), sizeof(wkv7c::LdsB), st, p);
+        } else if (g_bwd_variant == 6) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::bwd_kernel_v4<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsB3));
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(wkv7c::bwd_kernel_v4<true>, grid, dim3(768), sizeof(wkv7c::LdsB3), st, p);
         } else {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::bwd_kernel_v3<true, BWD_V3_DEFAULT_MODE>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsB3));
