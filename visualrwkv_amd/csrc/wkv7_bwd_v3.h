@@ -113,14 +113,23 @@ DEVFN void bwd_scores(LdsB3& lds, BufB& B, int pw, int lane) {
         st8(&B.sc[pw - 1][0][c16][4 * g], hh); st8(&B.sc[pw - 1][1][c16][4 * g], ll);
     } else {
         f32x4 X = dot64<true, true>(lds.opnd[0], lds.opnd[1], lds.opnd[4], lds.opnd[5], c16, g);    // [t][s]
-        f32x4 XT = dot64<true, true>(lds.opnd[4], lds.opnd[5], lds.opnd[0], lds.opnd[1], c16, g);   // [s][t]
-        f32x4 Tc;
+        f32x4 XT, Tc;                                                                                // XT = [s][t]
+        // transpose through this wave's own output slot (B.sc[3], 1536 B, written for real below) instead of a second
+        // 64-deep product
+        float (*scratch)[20] = reinterpret_cast<float (*)[20]>(&B.sc[3][0][0][0]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             X[r] = (c16 < 4 * g + r) ? X[r] : 0.f;
-            XT[r] = (4 * g + r < c16) ? XT[r] : 0.f;
-            Tc[r] = X[r] + ((4 * g + r == c16) ? 1.f : 0.f);
+            scratch[4 * g + r][c16] = X[r];
         }
+        wave_lds_fence();
+        {
+            const float4 t4 = *reinterpret_cast<const float4*>(&scratch[c16][4 * g]);
+            XT[0] = t4.x; XT[1] = t4.y; XT[2] = t4.z; XT[3] = t4.w;
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tc[r] = X[r] + ((4 * g + r == c16) ? 1.f : 0.f);
 #pragma unroll
         for (int level = 0; level < 3; ++level) {
             const f32x4 XTn = DBL_BF16 ? regmm_bf16x3(X, XT) : regmm_f32(X, XT);         // (X^T)^2
@@ -148,20 +157,32 @@ DEVFN void st_dsc(LdsB3& lds, int slot, f32x4 d, int c16, int g, int mode) {
     st8(&lds.dsc[slot][0][c16][4 * g], h);
     st8(&lds.dsc[slot][1][c16][4 * g], l);
 }
+// Both orientations of a score gradient from ONE 64-deep product: d[r] at lane (g, c16) is D[4g+r][c16]; the image of
+// D^T is four 8-byte row stores (st_dsc), the image of D itself a 2-byte scatter -- instead of a second product
+// (8 ds_read_b128 + up to 6 MFMAs per wave and chunk; the LDS pipeline is one of the two things that bound the kernel).
+DEVFN void st_dsc_both(LdsB3& lds, int slot_t, int slot_n, f32x4 d, int c16, int g, bool inclusive) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int x = 4 * g + r;
+        d[r] = (inclusive ? (c16 <= x) : (c16 < x)) ? d[r] : 0.f;
+    }
+    uint2 h, l;
+    split4(d, h, l);
+    st8(&lds.dsc[slot_t][0][c16][4 * g], h);                 // image[c16][4g+r] = D[4g+r][c16]
+    st8(&lds.dsc[slot_t][1][c16][4 * g], l);
+    st_b16x4_T(lds.dsc[slot_n][0], 4 * g, c16, h);           // image[4g+r][c16] = D[4g+r][c16]
+    st_b16x4_T(lds.dsc[slot_n][1], 4 * g, c16, l);
+}
 DEVFN void bwd_dscores(LdsB3& lds, const BufB& B, int pw, int lane) {
     const int c16 = lane & 15, g = lane >> 4;
     if (pw == 0) {          // dM_za = tril_(dR SA^T)
-        st_dsc(lds, 1, dot64<true, true>(lds.dr[0], lds.dr[1], B.ti[2], B.ti[3], c16, g), c16, g, 0);
-        st_dsc(lds, 0, dot64<true, true>(B.ti[2], B.ti[3], lds.dr[0], lds.dr[1], c16, g), c16, g, 1);
+        st_dsc_both(lds, 1, 0, dot64<true, true>(lds.dr[0], lds.dr[1], B.ti[2], B.ti[3], c16, g), c16, g, false);
     } else if (pw == 1) {   // dM_zk = tril_(dR V^T)
-        st_dsc(lds, 3, dot64<true, false>(lds.dr[0], lds.dr[1], B.ti[0], B.ti[0], c16, g), c16, g, 0);
-        st_dsc(lds, 2, dot64<false, true>(B.ti[0], B.ti[0], lds.dr[0], lds.dr[1], c16, g), c16, g, 1);
+        st_dsc_both(lds, 3, 2, dot64<true, false>(lds.dr[0], lds.dr[1], B.ti[0], B.ti[0], c16, g), c16, g, false);
     } else if (pw == 2) {   // dM_qa = tril(dY SA^T)
-        st_dsc(lds, 5, dot64<false, true>(B.ti[1], B.ti[1], B.ti[2], B.ti[3], c16, g), c16, g, 2);
-        st_dsc(lds, 4, dot64<true, false>(B.ti[2], B.ti[3], B.ti[1], B.ti[1], c16, g), c16, g, 3);
+        st_dsc_both(lds, 5, 4, dot64<false, true>(B.ti[1], B.ti[1], B.ti[2], B.ti[3], c16, g), c16, g, true);
     } else {                // dM_qk = tril(dY V^T)
-        st_dsc(lds, 7, dot64<false, false>(B.ti[1], B.ti[1], B.ti[0], B.ti[0], c16, g), c16, g, 2);
-        st_dsc(lds, 6, dot64<false, false>(B.ti[0], B.ti[0], B.ti[1], B.ti[1], c16, g), c16, g, 3);
+        st_dsc_both(lds, 7, 6, dot64<false, false>(B.ti[1], B.ti[1], B.ti[0], B.ti[0], c16, g), c16, g, true);
     }
 }
 

@@ -159,13 +159,23 @@ DEVFN void scores_v3(BufF& B, int pw, int lane) {
         for (int r = 0; r < 4; ++r) d[r] = (4 * g + r <= c16) ? d[r] : 0.f;
         *reinterpret_cast<float4*>(&B.scf[0][c16][4 * g]) = make_float4(d[0], d[1], d[2], d[3]);
     } else {                                  // T^T in C layout by doubling, all on the f32 matrix core
-        f32x4 X = score_v3(B, 0, 4, c16, g), XT = score_v3(B, 4, 0, c16, g), TT;
+        // X = tril_strict(Zt Ah^T) in C layout; its transpose comes from a bounce through this wave's own output slot
+        // (scf[1], written for real at the end) instead of a second 64-deep score product: 4 + 1 LDS instructions
+        // instead of 8 ds_read_b128 + 6 MFMAs on the producers' critical path.
+        f32x4 X = score_v3(B, 0, 4, c16, g), XT, TT;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             X[r] = (c16 < 4 * g + r) ? X[r] : 0.f;
-            XT[r] = (4 * g + r < c16) ? XT[r] : 0.f;
-            TT[r] = XT[r] + ((4 * g + r == c16) ? 1.f : 0.f);
+            B.scf[1][4 * g + r][c16] = X[r];
         }
+        wave_lds_fence();
+        {
+            const float4 t4 = *reinterpret_cast<const float4*>(&B.scf[1][c16][4 * g]);     // X[c16][4g..4g+3]
+            XT[0] = t4.x; XT[1] = t4.y; XT[2] = t4.z; XT[3] = t4.w;
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) TT[r] = XT[r] + ((4 * g + r == c16) ? 1.f : 0.f);
 #pragma unroll
         for (int level = 0; level < 3; ++level) {
             const f32x4 X2 = regmm_bf16x3(XT, X);
