@@ -86,6 +86,15 @@ int vrwkv_ce_fwd_bf16(long nrows, int V, const void* logits, const long* labels,
 int vrwkv_ce_bwd_bf16(long nrows, int V, const void* logits, const long* labels, const float* row_w, const float* row_max,
                       const float* row_lse, const int* row_argmax, float l2_factor, void* dlogits, void* stream);
 
+/* WKV7 forward from / to an explicit state, for inference and stateful prefill (no counterpart in the reference, whose
+ * forward always starts from S = 0 and always writes its training checkpoints -- cuda/wkv7_cuda.cu:15,44-50).
+ * s0: optional (B,H,64,64) f32 initial state S[i][j] (i = value row, j = key column; NULL = zeros);
+ * s_final: optional output, same layout; s_ckpt / sa: the training outputs of vrwkv_wkv7_forward_bf16, optional here
+ * (22 of the forward's 24 written bytes per element are these two).  T % 16 == 0. */
+int vrwkv_wkv7_forward_state_bf16(int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
+                                  const void* z, const void* a, void* y, const float* s0, float* s_final, float* s_ckpt,
+                                  float* sa, void* stream);
+
 /* WKV7 single-token step with carried state (stateful generation; the reference re-runs the whole forward per new
  * token, VisualRWKV-v7/v7.00/src/model.py:513-529).  w..a, y: (B,H,64) bf16; state: (B,H,64,64) f32, S[i][j] with
  * i = value row, j = key column, updated in place.  (The training op's checkpoint `s` holds S^T.) */

@@ -27,6 +27,14 @@ int emu_wkv7_forward(int B, int T, int H, const void* w, const void* q, const vo
     return 0;
 }
 
+int emu_wkv7_forward_state(int B, int T, int H, const void* w, const void* q, const void* k, const void* v, const void* z,
+                           const void* a, void* y, const float* s0, float* s_final) {
+    wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
+                    (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, nullptr, nullptr, nullptr, s0, s_final};
+    emu::launch(dim3((unsigned)(B * H)), dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1>(p); });
+    return 0;
+}
+
 int emu_wkv7_backward(int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
                       const void* z, const void* a, const void* dy, const float* s, const float* sa,
                       void* dw, void* dq, void* dk, void* dv, void* dz, void* da) {

@@ -26,6 +26,24 @@ def test_forward_variants(emu_lib, variant):
     assert rel_rms(s, sr) < 2e-5 and rel_rms(sa, sar) < 2e-5
 
 
+def test_forward_from_state(emu_lib):
+    """Inference form of the producer/consumer forward: explicit initial state, final state out, no checkpoints / sa."""
+    from oracle.wkv7_oracle import wkv7_naive
+    B, T, H = 1, 32, 2
+    w, q, k, v, z, a, _ = make_inputs(B, T, H, seed=21)
+    g = torch.Generator().manual_seed(4)
+    s0 = (torch.randn(B, H, 64, 64, generator=g) * 0.3).contiguous()
+    y = torch.zeros_like(v)
+    s_fin = torch.zeros(B, H, 64, 64)
+    emu_lib.emu_wkv7_forward_state(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(y), P(s0), P(s_fin))
+    y_ref, s_ref = wkv7_naive(*[x.double() for x in (w, q, k, v, z, a)], state0=s0.double())
+    assert rel_rms(y.double(), y_ref) < 4e-3 and rel_rms(s_fin.double(), s_ref) < 2e-5
+    y2 = torch.zeros_like(v)
+    emu_lib.emu_wkv7_forward_state(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(y2), None, None)
+    y_ref0, _ = wkv7_naive(*[x.double() for x in (w, q, k, v, z, a)])
+    assert rel_rms(y2.double(), y_ref0) < 4e-3
+
+
 def test_backward(emu_lib):
     B, T, H, N = 1, 48, 2, 64
     w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=5)

@@ -25,10 +25,10 @@ def oracle_kernels(monkeypatch):
         ops = [i.view(B, T, HC // 64, 64) for i in (w, q, k, v, a, b)]
         return wkv7_naive(*ops)[0].reshape(B, T, HC)
 
-    def prefill(w, q, k, v, z, a):
+    def prefill(w, q, k, v, z, a, state0=None, segments=None):
         calls["prefill"] += 1
         assert w.shape[1] % 16 == 0
-        return wkv7_naive(w, q, k, v, z, a)
+        return wkv7_naive(w, q, k, v, z, a, state0=state0)
 
     def step(w, q, k, v, z, a, state):
         calls["step"] += 1
@@ -43,7 +43,7 @@ def oracle_kernels(monkeypatch):
 
     monkeypatch.setattr(rwkv7, "RWKV7State", F64State)
     monkeypatch.setattr(rwkv7, "RUN_CUDA_RWKV7g", full)
-    monkeypatch.setattr(wkv7, "wkv7_prefill", prefill)
+    monkeypatch.setattr(wkv7, "wkv7_forward_tparallel", prefill)
     monkeypatch.setattr(wkv7, "wkv7_step", step)
     return calls
 
@@ -73,10 +73,9 @@ def test_stateful_equals_full_forward(oracle_kernels, splits):
     got = torch.cat(outs, dim=1)
     assert state.n_tokens == 48
     assert rel_rms(got, full) < 1e-12
-    # whole chunks of a fresh context use the chunked kernel, everything else is stepped
-    first = splits[0]
-    assert oracle_kernels["prefill"] == (3 if first >= 16 else 0)
-    assert oracle_kernels["step"] == 3 * (48 - first // 16 * 16)
+    # whole chunks of every call go through the chunked kernel (continuing from the carried state), the rest is stepped
+    assert oracle_kernels["prefill"] == 3 * sum(1 for n in splits if n >= 16)
+    assert oracle_kernels["step"] == 3 * sum(n % 16 for n in splits)
 
 
 def test_last_only_and_state_isolation(oracle_kernels):

@@ -114,3 +114,45 @@ def test_generate_stateful_first_token_matches_generate():
     assert len(got[0]) == 8 and all(0 <= t < 65536 for t in got[0])
     assert got[0][0] == ref[0][0]
     assert got[1][0] == pytest.approx(ref[1][0], rel=3e-2, abs=3e-2)
+
+
+def test_forward_from_state_matches_oracle():
+    from visualrwkv_amd import wkv7
+    B, T, H = 2, 48, 3
+    ins = make_inputs(B, T, H, seed=31)[:6]
+    g = torch.Generator().manual_seed(6)
+    s0 = torch.randn(B, H, 64, 64, generator=g) * 0.3
+    y_ref, s_ref = wkv7_naive(*[x.double() for x in ins], state0=s0.double())
+    y, s = wkv7.wkv7_forward_state(*[x.cuda() for x in ins], s0.cuda())
+    assert rel_rms(y.double().cpu(), y_ref) < 4e-3 and rel_rms(s.double().cpu(), s_ref) < 2e-5
+    y0, s_0 = wkv7.wkv7_forward_state(*[x.cuda() for x in ins])
+    y_ref0, s_ref0 = wkv7_naive(*[x.double() for x in ins])
+    assert rel_rms(y0.double().cpu(), y_ref0) < 4e-3 and rel_rms(s_0.double().cpu(), s_ref0) < 2e-5
+
+
+@pytest.mark.parametrize("with_state", [False, True])
+def test_tparallel_forward_equals_sequential(with_state):
+    """Sequence-parallel forward (three launches over T-segments) == the sequential kernel."""
+    from visualrwkv_amd import wkv7
+    B, T, H, P = 1, 512, 4, 4
+    ins = [x.cuda() for x in make_inputs(B, T, H, seed=41)[:6]]
+    s0 = (torch.randn(B, H, 64, 64, generator=torch.Generator().manual_seed(8)) * 0.3).cuda() if with_state else None
+    y_seq, s_seq = wkv7.wkv7_forward_state(*ins, s0)
+    y_par, s_par = wkv7.wkv7_forward_tparallel(*ins, s0, segments=P)
+    assert rel_rms(y_par.float(), y_seq.float()) < 4e-3          # both rounded to bf16
+    assert rel_rms(s_par, s_seq) < 1e-4
+    assert wkv7.tparallel_segments(1, 32, 2624) >= 3 and wkv7.tparallel_segments(16, 32, 2624) == 1
+    with pytest.raises(ValueError):
+        wkv7.wkv7_forward_tparallel(*ins, None, segments=5)
+
+
+def test_stateful_chunk_continuation_uses_state():
+    """A second multi-chunk call continues from the carried state (previously only a fresh context used the chunked kernel)."""
+    m = _lm(fused=True)
+    x = torch.randn(1, 96, 256, device="cuda", dtype=torch.bfloat16)
+    with torch.no_grad():
+        full = m(x).float()
+    o1, st = m.forward_stateful(x[:, :32], None)
+    o2, st = m.forward_stateful(x[:, 32:], st)
+    got = torch.cat((o1, o2), dim=1).float()
+    assert rel_rms(got, full) < 2e-2

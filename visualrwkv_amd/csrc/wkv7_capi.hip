@@ -99,6 +99,25 @@ int vrwkv_wkv7_forward_bf16(int B, int T, int H, const void* w, const void* q, c
     return finish_launch();
 }
 
+int vrwkv_wkv7_forward_state_bf16(int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
+                                  const void* z, const void* a, void* y, const float* s0, float* s_final, float* s_ckpt,
+                                  float* sa, void* stream) {
+    int rc = check_common(B, T, H);
+    if (rc) return rc;
+    if (!w || !q || !k || !v || !z || !a || !y) return VRWKV_EINVAL;
+    if (misaligned(w) || misaligned(q) || misaligned(k) || misaligned(v) || misaligned(z) || misaligned(a) || misaligned(y) ||
+        (s0 && misaligned(s0)) || (s_final && misaligned(s_final)) || (s_ckpt && misaligned(s_ckpt)) || (sa && misaligned(sa)))
+        return VRWKV_EALIGN;
+    wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
+                    (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, s_ckpt, sa, nullptr, s0, s_final};
+    auto kern = &wkv7c::fwd_kernel_v3<false, false, 1>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sizeof(wkv7c::LdsF));
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((long)B * H)), dim3(512), sizeof(wkv7c::LdsF), (hipStream_t)stream, p);
+    return finish_launch();
+}
+
 int vrwkv_wkv7_backward_bf16(int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
                              const void* z, const void* a, const void* dy, const float* s, const float* sa,
                              void* dw, void* dq, void* dk, void* dv, void* dz, void* da, void* stream) {

@@ -249,12 +249,20 @@ __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
     f32x4 S[4];
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) S[jb] = zero4();
+    if (p.s0) {                                      // S^T[j = 16jb+4g+r][i = 16w+c16] = s0[i][j]: 4 consecutive j per load
+        const float* sp = p.s0 + ((size_t)blockIdx.x * N + 16 * wave + c16) * N + 4 * g;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            const float4 x = *reinterpret_cast<const float4*>(sp + 16 * jb);
+            S[jb][0] = x.x; S[jb][1] = x.y; S[jb][2] = x.z; S[jb][3] = x.w;
+        }
+    }
     // after quad_transpose lane (g, c16) owns row 4g + (c16&3) and the 4 consecutive columns 16w + (c16&~3)..+3
     const unsigned out_off = WIDE ? (unsigned)(4 * g + (c16 & 3)) * ts + 16u * wave + (c16 & ~3)
                                   : (unsigned)(4 * g) * ts + 16u * wave + c16;
-    float* psa = p.sa + head_base;
+    float* psa = p.sa ? p.sa + head_base : nullptr;
     uint16_t* py = p.y + head_base;
-    float* ps = p.s + (size_t)blockIdx.x * nchunk * N * N;
+    float* ps = p.s ? p.s + (size_t)blockIdx.x * nchunk * N * N : nullptr;
     const unsigned s_off = WIDE ? (unsigned)(4 * g + (c16 & 3)) * N + 16u * wave + (c16 & ~3)   // s[j = 16jb+4g+(c16&3)][i..i+3]
                                 : (unsigned)(4 * g) * N + 16u * wave + c16;
 
@@ -310,13 +318,13 @@ __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
             uint16_t* y_c = py + (size_t)c * L * ts;
             if (WIDE) {
                 const f32x4 sat = quad_transpose(SA), yt = quad_transpose(Y);
-                *reinterpret_cast<float4*>(sa_c + out_off) = make_float4(sat[0], sat[1], sat[2], sat[3]);
+                if (psa) *reinterpret_cast<float4*>(sa_c + out_off) = make_float4(sat[0], sat[1], sat[2], sat[3]);
                 *reinterpret_cast<uint2*>(y_c + out_off) = make_uint2(cvt_pk_bf16(yt[0], yt[1]), cvt_pk_bf16(yt[2], yt[3]));
             } else {
                 const uint32_t y01 = cvt_pk_bf16(Y[0], Y[1]), y23 = cvt_pk_bf16(Y[2], Y[3]);   // one v_cvt_pk per pair
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    sa_c[out_off + r * ts] = SA[r];
+                    if (psa) sa_c[out_off + r * ts] = SA[r];
                     y_c[out_off + r * ts] = (uint16_t)((r < 2 ? y01 : y23) >> (16 * (r & 1)));
                 }
             }
@@ -346,17 +354,24 @@ __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
             acc = mfma_16x16x32_bf16(ah, b2, acc);
             acc = mfma_16x16x32_bf16(al, b1, acc);
             S[jb] = acc;
-            if (WIDE) {
-                const f32x4 at = quad_transpose(acc);
-                *reinterpret_cast<float4*>(s_c + s_off + (unsigned)(16 * jb) * N) = make_float4(at[0], at[1], at[2], at[3]);
-            } else {
+            if (p.s) {
+                if (WIDE) {
+                    const f32x4 at = quad_transpose(acc);
+                    *reinterpret_cast<float4*>(s_c + s_off + (unsigned)(16 * jb) * N) = make_float4(at[0], at[1], at[2], at[3]);
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s_c[s_off + (unsigned)(16 * jb + r) * N] = acc[r];
+                    for (int r = 0; r < 4; ++r) s_c[s_off + (unsigned)(16 * jb + r) * N] = acc[r];
+                }
             }
         }
         WKV_STAMP(4)
         block_sync_lds();                                        // B
         WKV_STAMP(5)
+    }
+    if (p.s_final) {
+        float* sp = p.s_final + ((size_t)blockIdx.x * N + 16 * wave + c16) * N + 4 * g;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) *reinterpret_cast<float4*>(sp + 16 * jb) = make_float4(S[jb][0], S[jb][1], S[jb][2], S[jb][3]);
     }
     WKV_STAMP_FLUSH(0, 0, 6)
 }

@@ -34,6 +34,9 @@ struct FwdArgs {
     float* s;                                // f32 (B,H,T/16,N,N)  holds S^T at chunk ends
     float* sa;                               // f32 (B,T,H,N)
     unsigned long long* dbg = nullptr;       // optional: per-phase cycle counts of workgroup 0 (profiling builds)
+    // inference / stateful extensions honoured by fwd_kernel_v3 only (s and sa may then be null = not written):
+    const float* s0 = nullptr;               // f32 (B,H,N,N) initial state S[i][j] (i = value row, j = key column)
+    float* s_final = nullptr;                // f32 (B,H,N,N) state after the last token, same layout
 };
 
 // ------------------------------------------------------------------------------------------

@@ -227,8 +227,9 @@ class RWKV7State:
     """Recurrent state of an RWKV-7 stack for stateful generation (the reference re-runs the
     whole sequence per generated token, src/model.py:513-529).  Per layer: the last token fed to the time-mix and
     channel-mix shifts (the reference's ZeroPad2d shift sees zeros before the first token) and the WKV state
-    S (B,H,64,64) fp32.  While a layer's S is still zero ("fresh"), whole 16-token chunks go through the training
-    forward kernel and only the ragged tail is stepped; afterwards every token is one `wkv7_step` launch."""
+    S (B,H,64,64) fp32.  Whole 16-token chunks go through the chunked MFMA forward kernel continuing from S (cut into
+    sequence-parallel segments when the heads alone cannot fill the chip); the ragged tail and single tokens are one
+    `wkv7_step` launch each."""
 
     def __init__(self, args, batch, device, dtype=torch.bfloat16):
         L, C = args.n_layer, args.n_embd
@@ -243,12 +244,13 @@ class RWKV7State:
         B, T, HC = r.shape
         ops = [i.view(B, T, HC // 64, 64) for i in (w, r, k, v, z, b)]      # the op's (w,q,k,v,z,a) order
         S, outs, t0 = self.S[layer], [], 0
-        if self.fresh[layer] and T >= CHUNK_LEN:
+        if T >= CHUNK_LEN:                              # whole chunks through the chunked MFMA kernel, from the carried state
             t0 = T // CHUNK_LEN * CHUNK_LEN
-            y, s_end = wkv7.wkv7_prefill(*[i[:, :t0].contiguous() for i in ops])
+            head = [i[:, :t0].contiguous() for i in ops]
+            y, s_end = wkv7.wkv7_forward_tparallel(*head, None if self.fresh[layer] else S)
             S.copy_(s_end)
             outs.append(y)
-        for t in range(t0, T):
+        for t in range(t0, T):                          # ragged tail / single tokens: one step launch each
             outs.append(wkv7.wkv7_step(*[i[:, t].contiguous() for i in ops], S).unsqueeze(1))
         self.fresh[layer] = False
         return (outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)).view(B, T, HC)

@@ -172,16 +172,73 @@ def RUN_CUDA_RWKV7g(q, w, k, v, a, b):
 # Stateful generation.  Not in the reference, whose generate() re-runs the full forward for
 # every new token (src/model.py:513-529); same recurrence, state carried between calls.
 # ---------------------------------------------------------------------------------------------------------------
-def wkv7_prefill(w, q, k, v, z, a):
-    """(B,T,H,64) bf16, T % 16 == 0, zero initial state -> (y, S) with S (B,H,64,64) fp32 in [value row][key col]
-    order (the training op's last checkpoint, which holds S^T -- cuda/wkv7_cuda.cu:36-41 -- transposed back)."""
-    B, T, H, C = w.shape
-    assert T % CHUNK_LEN == 0 and T > 0
+def wkv7_forward_state(w, q, k, v, z, a, state0=None, want_state=True):
+    """Forward from an explicit state, without the training by-products: (B,T,H,64) bf16 inputs, T % 16 == 0,
+    state0 (B,H,64,64) fp32 in [value row][key column] order or None (= zeros).  Returns (y, final state or None).
+    The kernel neither writes the chunk checkpoints nor `sa` (22 of the training forward's 24 output bytes per element)."""
+    B, T, H = _dims(w)
+    for n, t in zip("wqkvza", (w, q, k, v, z, a)):
+        _check_act(n, t, B, T, H)
+    if state0 is not None and (state0.dtype != torch.float32 or not state0.is_contiguous()
+                               or tuple(state0.shape) != (B, H, HEAD_SIZE, HEAD_SIZE) or state0.device != w.device):
+        raise ValueError(f"wkv7: state0 must be a contiguous fp32 ({B},{H},{HEAD_SIZE},{HEAD_SIZE}) tensor on {w.device}")
     y = torch.empty_like(v)
-    s = torch.empty(B, H, T // CHUNK_LEN, C, C, dtype=torch.float32, device=w.device)
-    sa = torch.empty(B, T, H, C, dtype=torch.float32, device=w.device)
-    torch.ops.wind_backstepping.forward(w, q, k, v, z, a, y, s, sa)
-    return y, s[:, :, -1].transpose(-1, -2).contiguous()
+    s_fin = torch.empty(B, H, HEAD_SIZE, HEAD_SIZE, dtype=torch.float32, device=w.device) if want_state else None
+    lib = hip_lib.load()
+    with torch.cuda.device(w.device):
+        rc = lib.vrwkv_wkv7_forward_state_bf16(B, T, H, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), z.data_ptr(),
+                                               a.data_ptr(), y.data_ptr(), state0.data_ptr() if state0 is not None else 0,
+                                               s_fin.data_ptr() if want_state else 0, 0, 0,
+                                               torch.cuda.current_stream(w.device).cuda_stream)
+    hip_lib.check(rc, "vrwkv_wkv7_forward_state_bf16")
+    return y, s_fin
+
+
+def wkv7_prefill(w, q, k, v, z, a, state0=None):
+    """(y, state after the last token) for a whole number of 16-token chunks, continuing from `state0` (None: empty)."""
+    return wkv7_forward_state(w, q, k, v, z, a, state0, want_state=True)
+
+
+def tparallel_segments(B, H, T, n_cu=256, max_segments=16):
+    """How many T-segments to cut a sequence into so that B*H*segments workgroups fill the chip:
+    1 when the heads alone fill it or the sequence is too short to amortise the three passes."""
+    if B * H >= n_cu or T < 256:
+        return 1
+    p = min(max_segments, max(1, n_cu // (B * H)), T // 64)
+    while p > 1 and (T % p != 0 or (T // p) % CHUNK_LEN != 0):
+        p -= 1
+    return p if p >= 3 else 1                       # three passes: fewer than 3 segments cannot win
+
+
+def wkv7_forward_tparallel(w, q, k, v, z, a, state0=None, segments=None):
+    """Sequence-parallel forward for few heads (inference prefill: B*H = 32 workgroups on 256 CUs).  The recurrence
+    is linear in the state, S_end = S_start M_p + B_p per segment p, with M_p (64x64, acting on the key index) and
+    B_p independent of S_start.  Three launches over all B*P*H (segment, head) pairs:
+      1. B_p  : every segment from S = 0                       2. M_p : every segment from S = I with v = 0
+      (then P tiny 64x64 products per head chain the segment-start states)
+      3. y    : every segment from its true start state.
+    Returns (y, final state)."""
+    B, T, H = _dims(w)
+    P = segments if segments is not None else tparallel_segments(B, H, T)
+    if P <= 1:
+        return wkv7_forward_state(w, q, k, v, z, a, state0)
+    if T % P != 0 or (T // P) % CHUNK_LEN != 0:
+        raise ValueError(f"wkv7: T = {T} cannot be cut into {P} segments of whole {CHUNK_LEN}-token chunks")
+    Ts = T // P
+    seg = [t.view(B * P, Ts, H, HEAD_SIZE) for t in (w, q, k, v, z, a)]          # contiguous views, no copies
+    _, b_p = wkv7_forward_state(*seg)                                              # (B*P,H,64,64)
+    eye = torch.eye(HEAD_SIZE, dtype=torch.float32, device=w.device).expand(B * P, H, HEAD_SIZE, HEAD_SIZE).contiguous()
+    _, m_p = wkv7_forward_state(seg[0], seg[1], seg[2], torch.zeros_like(seg[3]), seg[4], seg[5], eye)
+    b_p = b_p.view(B, P, H, HEAD_SIZE, HEAD_SIZE)
+    m_p = m_p.view(B, P, H, HEAD_SIZE, HEAD_SIZE)
+    cur = state0 if state0 is not None else torch.zeros(B, H, HEAD_SIZE, HEAD_SIZE, dtype=torch.float32, device=w.device)
+    starts = []
+    for p in range(P):
+        starts.append(cur)
+        cur = torch.matmul(cur, m_p[:, p]) + b_p[:, p]
+    s0 = torch.stack(starts, dim=1).view(B * P, H, HEAD_SIZE, HEAD_SIZE).contiguous()
+    y, _ = wkv7_forward_state(*seg, s0, want_state=False)
+    return y.view(B, T, H, HEAD_SIZE), cur
 
 
 def wkv7_step(w, q, k, v, z, a, state):
