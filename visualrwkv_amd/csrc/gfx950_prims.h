@@ -160,7 +160,7 @@ DEVFN unsigned long long clock64_() { return __builtin_readcyclecounter(); }
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 DEVFN uint2 lds_read_tr16(const uint16_t* p) {
     typedef __attribute__((address_space(3))) s16x4* lds_ptr;
-    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(uint32_t)(uintptr_t)p);
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(uintptr_t)(uint32_t)(uintptr_t)p);   // low 32 bits of a generic LDS pointer = LDS offset
     return __builtin_bit_cast(uint2, v);
 }
 
