@@ -156,3 +156,19 @@ def test_stateful_chunk_continuation_uses_state():
     o2, st = m.forward_stateful(x[:, 32:], st)
     got = torch.cat((o1, o2), dim=1).float()
     assert rel_rms(got, full) < 2e-2
+
+
+def test_graph_decoder_matches_eager_steps():
+    """The HIP-graph-captured decode step advances the same state and returns the same logits as the eager step."""
+    m = _lm(fused=True)
+    x = torch.randn(1, 40, 256, device="cuda", dtype=torch.bfloat16)
+    _, st_a = m.forward_stateful(x[:, :32], None)
+    _, st_b = m.forward_stateful(x[:, :32], None)
+    dec = m.make_decoder(st_b)
+    for t in range(32, 40):
+        la, st_a = m.forward_stateful(x[:, t:t + 1], st_a, last_only=True)
+        lb = dec(x[:, t:t + 1])
+        assert rel_rms(lb.float(), la.float()) < 1e-3
+    for a, b in zip(st_a.S + st_a.att_x, st_b.S + st_b.att_x):
+        assert rel_rms(b.float(), a.float()) < 1e-3
+    assert st_b.n_tokens == st_a.n_tokens == 40

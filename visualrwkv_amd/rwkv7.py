@@ -111,7 +111,7 @@ class RWKV_Tmix_x070(nn.Module):
             xx = time_shift(x) - x
         else:
             xx = torch.cat((state.att_x[self.layer_id].unsqueeze(1), x[:, :-1]), dim=1) - x
-            state.att_x[self.layer_id] = x[:, -1]
+            state.att_x[self.layer_id].copy_(x[:, -1])          # in place: the state tensors are stable addresses (HIP graphs)
         xr = x + xx * self.x_r
         xw = x + xx * self.x_w
         xk = x + xx * self.x_k
@@ -170,7 +170,7 @@ class RWKV_CMix_x070(nn.Module):
             xx = time_shift(x) - x
         else:
             xx = torch.cat((state.ffn_x[self.layer_id].unsqueeze(1), x[:, :-1]), dim=1) - x
-            state.ffn_x[self.layer_id] = x[:, -1]
+            state.ffn_x[self.layer_id].copy_(x[:, -1])
         k = x + xx * self.x_k
         k = torch.relu(self.key(k)) ** 2
         return self.value(k)
@@ -322,3 +322,39 @@ class RWKV(nn.Module):
         if last_only:
             x = x[:, -1]
         return self.head(self.ln_out(x)), state
+
+    def make_decoder(self, state):
+        """A single-token decode step captured in a HIP graph (the eager step is ~1000 small launches for 24 layers and
+        is bound by launch overhead, not by the GPU).  Returns `step(x_emb (B,1,C)) -> logits (B,V)`; `state` is
+        advanced in place by every call, exactly as `forward_stateful(x_emb, state, last_only=True)` would."""
+        return GraphDecoder(self, state)
+
+
+class GraphDecoder:
+    def __init__(self, rwkv: "RWKV", state: RWKV7State):
+        self.rwkv, self.state = rwkv, state
+        p = next(rwkv.parameters())
+        B = state.S[0].shape[0]
+        self.x_in = torch.zeros(B, 1, rwkv.args.n_embd, device=p.device, dtype=p.dtype)
+        keep = [t.clone() for t in state.att_x + state.ffn_x + state.S]       # warm-up and capture run the step for real
+        fresh, n_tok = list(state.fresh), state.n_tokens
+        side = torch.cuda.Stream(device=p.device)
+        side.wait_stream(torch.cuda.current_stream(p.device))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):
+                rwkv.forward_stateful(self.x_in, state, last_only=True)
+        torch.cuda.current_stream(p.device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.logits, _ = rwkv.forward_stateful(self.x_in, state, last_only=True)
+        for dst, src in zip(state.att_x + state.ffn_x + state.S, keep):
+            dst.copy_(src)
+        state.fresh, state.n_tokens = fresh, n_tok
+
+    @torch.no_grad()
+    def __call__(self, x_emb):
+        self.x_in.copy_(x_emb)
+        self.graph.replay()
+        self.state.n_tokens += 1
+        self.state.fresh = [False] * len(self.state.fresh)
+        return self.logits

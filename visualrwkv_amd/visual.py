@@ -158,7 +158,8 @@ class VisualRWKV(nn.Module):
         return toks, lgs, prs
 
     @torch.no_grad()
-    def generate_stateful(self, input_ids, images, do_sample, temperature, top_p, max_new_tokens, stop_token_idx):
+    def generate_stateful(self, input_ids, images, do_sample, temperature, top_p, max_new_tokens, stop_token_idx,
+                          use_graph=False):
         """`generate` with the recurrent state carried between tokens: one prefill over the prompt, then one
         single-token step per new token (O(1) per token instead of re-running the whole sequence).
         The prompt is left-padded once, like `RWKV.forward` pads it (src/model.py:301-307), so the first token
@@ -173,6 +174,7 @@ class VisualRWKV(nn.Module):
         rem = x.size(1) % CHUNK_LEN
         x = self.rwkv.pad_left(x, CHUNK_LEN - rem if rem else 0)
         logits, state = self.rwkv.forward_stateful(x, None, last_only=True)
+        decoder = self.rwkv.make_decoder(state) if use_graph and x.is_cuda else None
         toks, lgs, prs = [], [], []
         for _ in range(max_new_tokens):
             nxt = torch.argmax(logits, dim=-1, keepdim=True)
@@ -181,5 +183,8 @@ class VisualRWKV(nn.Module):
             prs.append(torch.softmax(logits, dim=-1).gather(-1, nxt).item())
             if toks[-1] == stop_token_idx or len(toks) == max_new_tokens:
                 break
-            logits, state = self.rwkv.forward_stateful(self.rwkv.emb(nxt), state, last_only=True)
+            if decoder is not None:
+                logits = decoder(self.rwkv.emb(nxt))
+            else:
+                logits, state = self.rwkv.forward_stateful(self.rwkv.emb(nxt), state, last_only=True)
         return toks, lgs, prs
