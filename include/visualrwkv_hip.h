@@ -129,6 +129,9 @@ int vrwkv_wkv7_set_backward_variant(int variant);
  *   relusq : relu(h)^2, model.py:225.
  */
 int vrwkv_mix_fwd_bf16(long ntok, int T, int C, int M, const void* x, const void* const* mu, void* const* out, void* stream);
+/* same, for stateful inference: x_prev (ntok/T, C) bf16 = the token before the first one of every sample (NULL: zeros) */
+int vrwkv_mix_fwd_prev_bf16(long ntok, int T, int C, int M, const void* x, const void* x_prev, const void* const* mu,
+                            void* const* out, void* stream);
 long vrwkv_param_grad_ws_floats(long ntok, int C, int nvec);
 int vrwkv_mix_bwd_bf16(long ntok, int T, int C, int M, const void* x, const void* const* mu, const void* const* dout,
                        void* dx, float* dmu, float* ws, void* stream);

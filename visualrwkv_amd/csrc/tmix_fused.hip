@@ -72,7 +72,8 @@ struct MPtrs6 { uint16_t* p[MAXM]; };
 
 // ---------------------------------------------------------------------------------------------- F1 / F5: shift + lerps
 template <int M>
-__global__ void mix_fwd_kernel(long ntok, int T, int C, const uint16_t* __restrict__ x, Ptrs6 mu, MPtrs6 out) {
+__global__ void mix_fwd_kernel(long ntok, int T, int C, const uint16_t* __restrict__ x, const uint16_t* __restrict__ x_prev,
+                               Ptrs6 mu, MPtrs6 out) {
     const int c0 = threadIdx.x * 8;
     V8 m[M];
 #pragma unroll
@@ -83,6 +84,10 @@ __global__ void mix_fwd_kernel(long ntok, int T, int C, const uint16_t* __restri
         V8 xx;
         if (n % T != 0) {
             const V8 xp = ld8f(x + (n - 1) * C + c0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xx.f[e] = xp.f[e] - xv.f[e];
+        } else if (x_prev) {                       // stateful inference: the token before the first one of sample n / T
+            const V8 xp = ld8f(x_prev + (n / T) * C + c0);
 #pragma unroll
             for (int e = 0; e < 8; ++e) xx.f[e] = xp.f[e] - xv.f[e];
         } else {
@@ -438,13 +443,18 @@ inline int done() { hipError_t e = hipGetLastError(); return e == hipSuccess ? V
 extern "C" {
 
 int vrwkv_mix_fwd_bf16(long ntok, int T, int C, int M, const void* x, const void* const* mu, void* const* out, void* stream) {
+    return vrwkv_mix_fwd_prev_bf16(ntok, T, C, M, x, nullptr, mu, out, stream);
+}
+
+int vrwkv_mix_fwd_prev_bf16(long ntok, int T, int C, int M, const void* x, const void* x_prev, const void* const* mu,
+                            void* const* out, void* stream) {
     if (ntok <= 0 || T <= 0 || !x || !mu || !out || (M != 1 && M != 6)) return VRWKV_EINVAL;
     if (!ok_c(C) || ntok % T != 0) return VRWKV_ESHAPE;
     Ptrs6 m{}; MPtrs6 o{};
     for (int i = 0; i < M; ++i) { m.p[i] = (const uint16_t*)mu[i]; o.p[i] = (uint16_t*)out[i]; if (!m.p[i] || !o.p[i]) return VRWKV_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
-    if (M == 6) hipLaunchKernelGGL(mix_fwd_kernel<6>, tok_grid(ntok), dim3(C / 8), 0, st, ntok, T, C, (const uint16_t*)x, m, o);
-    else hipLaunchKernelGGL(mix_fwd_kernel<1>, tok_grid(ntok), dim3(C / 8), 0, st, ntok, T, C, (const uint16_t*)x, m, o);
+    if (M == 6) hipLaunchKernelGGL(mix_fwd_kernel<6>, tok_grid(ntok), dim3(C / 8), 0, st, ntok, T, C, (const uint16_t*)x, (const uint16_t*)x_prev, m, o);
+    else hipLaunchKernelGGL(mix_fwd_kernel<1>, tok_grid(ntok), dim3(C / 8), 0, st, ntok, T, C, (const uint16_t*)x, (const uint16_t*)x_prev, m, o);
     return done();
 }
 

@@ -366,6 +366,52 @@ def tmix_forward(m, x, v_first):
     return m.output(y), v_first
 
 
+def mix_prev(x, x_prev, *mus):
+    """Inference-only `mix` whose shift sees `x_prev` (B,C) before the first token instead of zeros (stateful decode)."""
+    B, T, C = x.shape
+    x = x.contiguous()
+    x_prev = x_prev.contiguous()
+    mus_c = [m.reshape(C).contiguous() for m in mus]
+    _chk(x, x_prev, *mus_c)
+    outs = [torch.empty_like(x) for _ in mus]
+    rc = hip_lib.load().vrwkv_mix_fwd_prev_bf16(B * T, T, C, len(mus), x.data_ptr(), x_prev.data_ptr(), _ptr_array(mus_c),
+                                                _ptr_array(outs), _stream(x))
+    hip_lib.check(rc, "vrwkv_mix_fwd_prev_bf16")
+    return tuple(outs)
+
+
+@torch.no_grad()
+def tmix_forward_stateful(m, x, v_first, state):
+    """`tmix_forward` continuing from `state` (an RWKV7State): fused glue kernels, WKV through state.wkv."""
+    lid = m.layer_id
+    xr, xw, xk, xv, xa, xg = mix_prev(x, state.att_x[lid], m.x_r, m.x_w, m.x_k, m.x_v, m.x_a, m.x_g)
+    state.att_x[lid].copy_(x[:, -1])
+    r = m.receptance(xr)
+    w = decay(torch.tanh(xw @ m.w1) @ m.w2, m.w0)
+    k = m.key(xk)
+    v = m.value(xv)
+    al = (xa @ m.a1) @ m.a2
+    g = torch.sigmoid(xg @ m.g1) @ m.g2
+    if lid == 0:
+        v_first = v
+        k2, z, b = kva(k, None, None, None, al, m.k_k, m.k_a, m.a0, None)
+        v2 = v
+    else:
+        vl = (xv @ m.v1) @ m.v2
+        k2, v2, z, b = kva(k, v, v_first, vl, al, m.k_k, m.k_a, m.a0, m.v0)
+    y = state.wkv(lid, r, w, k2, v2, z, b)
+    y = post(y, r, k2, v2, g, m.ln_x.weight, m.ln_x.bias, m.r_k, m.ln_x.eps)
+    return m.output(y), v_first
+
+
+@torch.no_grad()
+def cmix_forward_stateful(m, x, state):
+    lid = m.layer_id
+    (k,) = mix_prev(x, state.ffn_x[lid], m.x_k)
+    state.ffn_x[lid].copy_(x[:, -1])
+    return m.value(relu_sq(m.key(k)))
+
+
 def cmix_forward(m, x):
     """RWKV_CMix_x070.forward (src/model.py:221-227)."""
     (k,) = mix(x, m.x_k)

@@ -31,6 +31,7 @@ PROTOTYPES = {
     "vrwkv_wkv7_set_forward_variant": (_c_int, [_c_int]),
     "vrwkv_wkv7_set_backward_variant": (_c_int, [_c_int]),
     "vrwkv_mix_fwd_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int, _c_int] + [_c_void_p] * 4),
+    "vrwkv_mix_fwd_prev_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int, _c_int] + [_c_void_p] * 5),
     "vrwkv_param_grad_ws_floats": (ctypes.c_long, [ctypes.c_long, _c_int, _c_int]),
     "vrwkv_mix_bwd_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int, _c_int] + [_c_void_p] * 7),
     "vrwkv_decay_fwd_bf16": (_c_int, [ctypes.c_long, _c_int] + [_c_void_p] * 4),

@@ -104,9 +104,12 @@ class RWKV_Tmix_x070(nn.Module):
         """`state` (an RWKV7State, inference only) carries the previous token and the WKV state across calls."""
         B, T, C = x.size()
         H = self.n_head
-        if state is None and getattr(self.args, "fused", False) and x.is_cuda:
+        if getattr(self.args, "fused", False) and x.is_cuda:
             from . import fused
-            return fused.tmix_forward(self, x, v_first)
+            if state is None:
+                return fused.tmix_forward(self, x, v_first)
+            if not torch.is_grad_enabled() and x.dtype == torch.bfloat16:
+                return fused.tmix_forward_stateful(self, x, v_first, state)
         if state is None:
             xx = time_shift(x) - x
         else:
@@ -163,9 +166,12 @@ class RWKV_CMix_x070(nn.Module):
         self.value.weight.data.zero_()
 
     def forward(self, x, state=None):
-        if state is None and getattr(self.args, "fused", False) and x.is_cuda:
+        if getattr(self.args, "fused", False) and x.is_cuda:
             from . import fused
-            return fused.cmix_forward(self, x)
+            if state is None:
+                return fused.cmix_forward(self, x)
+            if not torch.is_grad_enabled() and x.dtype == torch.bfloat16:
+                return fused.cmix_forward_stateful(self, x, state)
         if state is None:
             xx = time_shift(x) - x
         else:
