@@ -95,6 +95,13 @@ int vrwkv_wkv7_forward_state_bf16(int B, int T, int H, const void* w, const void
                                   const void* z, const void* a, void* y, const float* s0, float* s_final, float* s_ckpt,
                                   float* sa, void* stream);
 
+/* Batched GEMV for single-token decode: y_j = act_j(W_j x_j) (+ res_j) for n_jobs <= 8 independent products in one
+ * launch (at T = 1 every nn.Linear / LoRA product of RWKV_Tmix_x070 / RWKV_CMix_x070.forward, src/model.py:175-194,222-225,
+ * is a GEMV).  W_j: (N_j,K_j) bf16 row-major, x_j: (B,K_j), res_j: (B,N_j) or NULL, y_j: (B,N_j); B <= 4, K_j % 8 == 0,
+ * B * max K_j <= 16384; act: 0 none, 1 tanh, 2 sigmoid, 3 relu^2. */
+int vrwkv_gemv_multi_bf16(int n_jobs, int B, const void* const* W, const void* const* x, const void* const* res,
+                          void* const* y, const int* N, const int* K, const int* act, void* stream);
+
 /* WKV7 single-token step with carried state (stateful generation; the reference re-runs the whole forward per new
  * token, VisualRWKV-v7/v7.00/src/model.py:513-529).  w..a, y: (B,H,64) bf16; state: (B,H,64,64) f32, S[i][j] with
  * i = value row, j = key column, updated in place.  (The training op's checkpoint `s` holds S^T.) */

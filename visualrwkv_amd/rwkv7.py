@@ -322,8 +322,16 @@ class RWKV(nn.Module):
         if state is None:
             state = RWKV7State(self.args, x.size(0), x.device, x.dtype)
         v_first = torch.empty_like(x)
+        use_decode = False
+        if getattr(self.args, "fused", False) and x.shape[1] == 1:
+            from . import decode
+            use_decode = decode.supported(x) and x.shape[0] * 4 * self.args.n_embd <= 16384
         for block in self.blocks:
-            x, v_first = block(x, v_first, state)
+            if use_decode:                               # single token: batched-GEMV step (decode.py)
+                x, v_first = decode.block_decode(block, x, v_first, state)
+                state.fresh[block.layer_id] = False
+            else:
+                x, v_first = block(x, v_first, state)
         state.n_tokens += x.size(1)
         if last_only:
             x = x[:, -1]
