@@ -97,10 +97,27 @@ int vrwkv_wkv7_forward_state_bf16(int B, int T, int H, const void* w, const void
 
 /* Batched GEMV for single-token decode: y_j = act_j(W_j x_j) (+ res_j) for n_jobs <= 8 independent products in one
  * launch (at T = 1 every nn.Linear / LoRA product of RWKV_Tmix_x070 / RWKV_CMix_x070.forward, src/model.py:175-194,222-225,
- * is a GEMV).  W_j: (N_j,K_j) bf16 row-major, x_j: (B,K_j), res_j: (B,N_j) or NULL, y_j: (B,N_j); B <= 4, K_j % 8 == 0,
- * B * max K_j <= 16384; act: 0 none, 1 tanh, 2 sigmoid, 3 relu^2. */
+ * is a GEMV).  W_j: (N_j,K_j) bf16 row-major, x_j: (B,K_j), res_j: (B,N_j) or NULL, y_j: (B,N_j); B <= 4, K_j % 8 == 0;
+ * act: 0 none, 1 tanh, 2 sigmoid, 3 relu^2. */
 int vrwkv_gemv_multi_bf16(int n_jobs, int B, const void* const* W, const void* const* x, const void* const* res,
                           void* const* y, const int* N, const int* K, const int* act, void* stream);
+
+/* Decode step, fused glue (T = 1; replaces the launch-bound chains of src/model.py:166-194,247-254 for one token).
+ * ln_mix: h = LayerNorm(x) (src/model.py:250,253: ln1 / ln2), out_j = h + (x_prev - h) * mu_j for M <= 6 lerps
+ * (src/model.py:169-173,222-223 with the shift reading the carried row), then x_prev = h.  x, x_prev, out_j: (B,C) bf16;
+ * ln_w, ln_b, mu_j: (C) bf16; C % 8 == 0, C <= 8192. */
+int vrwkv_decode_ln_mix_bf16(int B, int C, int M, const void* x, const void* ln_w, const void* ln_b, float eps,
+                             void* x_prev, const void* const* mu, void* const* out, void* stream);
+/* tmix_head, one workgroup per (b, head): second LoRA stage of w / a / g / v-gate (hid_i (B,D_i) bf16 hidden vectors
+ * with their activation applied, W2t_i (C,D_i) bf16 = the reference's w2, a2, g2, v2 parameters TRANSPOSED;
+ * src/model.py:176,181-183), decay soft-clamp (:176), k_k normalisation, k_a, value residual (:180-187), the WKV7 step
+ * of vrwkv_wkv7_step_bf16 on `state` in place, GroupNorm ln_x + r_k bonus + gate (:190-193).  r, k, v, out: (B,C) bf16
+ * with C = 64 H; v_first / v0 / hid[3] / W2t[3] NULL on layer 0; D_i % 32 == 0. */
+int vrwkv_decode_tmix_head_bf16(int B, int H, const void* r, const void* k, const void* v, const void* v_first,
+                                const void* const* hid, const void* const* W2t, const int* D,
+                                const void* w0, const void* a0, const void* v0, const void* k_k, const void* k_a,
+                                const void* r_k, const void* ln_w, const void* ln_b, float eps,
+                                float* state, void* out, void* stream);
 
 /* WKV7 single-token step with carried state (stateful generation; the reference re-runs the whole forward per new
  * token, VisualRWKV-v7/v7.00/src/model.py:513-529).  w..a, y: (B,H,64) bf16; state: (B,H,64,64) f32, S[i][j] with

@@ -208,3 +208,57 @@ def test_decode_step_path_matches_module_path():
         assert rel_rms(lg.float(), ref[i].float()) < 2e-2
     for a, b in zip(st_a.S, st_b.S):
         assert rel_rms(b, a) < 2e-2
+
+
+@pytest.mark.parametrize("B,C,M", [(1, 256, 6), (3, 2048, 1), (2, 4096, 6)])
+def test_decode_ln_mix_matches_torch(B, C, M):
+    """vrwkv_decode_ln_mix_bf16 against LayerNorm + shift + lerps in fp32 (src/model.py:169-173,250)."""
+    from visualrwkv_amd import decode
+    g = torch.Generator(device="cuda").manual_seed(C + M)
+    rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    x, prev = (rn(B, C) * 2 + 0.3).bfloat16(), rn(B, C).bfloat16()
+    ln = torch.nn.LayerNorm(C).cuda().bfloat16()
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.2 * rn(C)); ln.bias.copy_(0.1 * rn(C))
+    mus = [torch.rand(1, 1, C, device="cuda", generator=g).bfloat16() for _ in range(M)]
+    h = torch.nn.functional.layer_norm(x.float(), (C,), ln.weight.float(), ln.bias.float(), ln.eps).bfloat16().float()
+    want = [h + (prev.float() - h) * m.view(C).float() for m in mus]
+    carried = prev.clone()
+    got = decode.ln_mix(x, ln, carried, mus)
+    assert rel_rms(carried.float(), h) < 3e-3
+    for a, b in zip(got, want):
+        assert rel_rms(a.float(), b) < 5e-3
+
+
+@pytest.mark.parametrize("B,layer", [(1, 0), (3, 1)])
+def test_decode_tmix_head_matches_unfused_chain(B, layer):
+    """vrwkv_decode_tmix_head_bf16 against the kernels it fuses (LoRA second stage in torch, decay / kva / wkv7_step /
+    post through their own C-ABI entries) on the same inputs and state."""
+    from visualrwkv_amd import decode, fused, wkv7
+    m = _lm(fused=True).blocks[layer].att
+    C, H = 256, 4
+    g = torch.Generator(device="cuda").manual_seed(10 + B)
+    rn = lambda *s: (torch.randn(*s, device="cuda", generator=g) * 0.5).bfloat16()
+    with torch.no_grad():                      # the default init leaves several of these at zero
+        W2 = [m.w2, m.a2, m.g2] + ([m.v2] if layer > 0 else [])
+        for p in W2:
+            p.copy_(rn(*p.shape) * 0.2)
+    r, k, v, vf = rn(B, C), rn(B, C), rn(B, C), rn(B, C)
+    hidden = [torch.tanh(rn(B, m.w2.shape[0]).float()).bfloat16(), rn(B, m.a2.shape[0]),
+              torch.sigmoid(rn(B, m.g2.shape[0]).float()).bfloat16()] + ([rn(B, m.v2.shape[0])] if layer > 0 else [])
+    S0 = torch.randn(B, H, 64, 64, device="cuda", generator=g) * 0.1
+    sh = (B, 1, C)
+    lo = [(h @ W).view(sh) for h, W in zip(hidden, W2)]
+    w = fused.decay(lo[0], m.w0)
+    if layer == 0:
+        k2, z, b = fused.kva(k.view(sh), None, None, None, lo[1], m.k_k, m.k_a, m.a0, None)
+        v2 = v.view(sh)
+    else:
+        k2, v2, z, b = fused.kva(k.view(sh), v.view(sh), vf.view(sh), lo[3], lo[1], m.k_k, m.k_a, m.a0, m.v0)
+    S_ref = S0.clone()
+    y = wkv7.wkv7_step(*[t.reshape(B, H, 64).contiguous() for t in (w, r, k2, v2, z, b)], S_ref)
+    want = fused.post(y.view(sh), r.view(sh), k2, v2, lo[2], m.ln_x.weight, m.ln_x.bias, m.r_k, m.ln_x.eps).view(B, C)
+    S = S0.clone()
+    got = decode.tmix_head(m, r, k, v, vf if layer > 0 else None, hidden, S)
+    assert rel_rms(S, S_ref) < 2e-3
+    assert rel_rms(got.float(), want.float()) < 1e-2

@@ -4,9 +4,13 @@
 // otherwise launch-bound -- the library issues one kernel per projection and activation.
 //
 // W_j: (N_j, K_j) bf16 row-major (nn.Linear layout; LoRA factors are pre-transposed by the caller), x_j: (B, K_j) bf16,
-// y_j: (B, N_j) bf16, B <= 4.  A row is reduced by a group of G = min(64, K/8) lanes (16-byte loads, 8 bf16 per lane
-// and step), so a wave handles 64/G rows at a time; x is staged once per workgroup in LDS as fp32.  fp32 accumulation,
-// one rounding at the end (the library GEMM it replaces also accumulates in fp32).
+// y_j: (B, N_j) bf16, B <= 4.  fp32 accumulation, one rounding at the end (the library GEMM it replaces also
+// accumulates in fp32).
+//   long rows (K >= 512): a wave owns 2 rows and walks them with 16-byte loads, 8 weight loads per lane in flight
+//   before the first use; x comes straight from global memory (every wave reads the same few KB: L1/L2 hits), so
+//   nothing is staged and no barrier delays the weight stream.  8 rows per workgroup: a 2048 x 2048 projection is
+//   256 workgroups, and the whole matrix is in flight at once -- the step is bound by one HBM round trip per launch.
+//   short rows (K < 512): a group of G = K/8 lanes per row, 64/G rows at a time, x staged in LDS as fp32.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/visualrwkv_hip.h"
@@ -16,7 +20,9 @@ namespace {
 
 constexpr int GV_MAX_JOBS = 8;
 constexpr int GV_MAX_B = 4;
-constexpr int GV_ROWS_PER_WG = 32;
+constexpr int GV_ROWS_PER_WG = 32;      // short-row jobs
+constexpr int GV_LONG_ROWS_PER_WG = 8;  // long-row jobs: 2 per wave
+constexpr int GV_LONG_KCHUNKS = 64;     // K >= 512
 constexpr int GV_THREADS = 256;
 
 struct GemvJob {
@@ -36,71 +42,78 @@ DEVFN float apply_act(float v, int act) {
     return v;
 }
 
+DEVFN void unpack8(const uint4& u, float* f) {
+    f[0] = bf16_lo(u.x); f[1] = bf16_hi(u.x); f[2] = bf16_lo(u.y); f[3] = bf16_hi(u.y);
+    f[4] = bf16_lo(u.z); f[5] = bf16_hi(u.z); f[6] = bf16_lo(u.w); f[7] = bf16_hi(u.w);
+}
+
 __global__ __launch_bounds__(GV_THREADS) void gemv_multi_kernel(GemvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];         // [B][K]
+    extern __shared__ __attribute__((aligned(16))) float xs[];         // [B][K], short-row jobs only
     int j = 0;
 #pragma unroll
     for (int t = 1; t < GV_MAX_JOBS; ++t) j += (t < a.n_jobs && (int)blockIdx.x >= a.job[t].wg_begin) ? 1 : 0;
     const GemvJob job = a.job[j];
     const int K = job.K, N = job.N, B = a.B;
-    for (int i = threadIdx.x * 8; i < B * K; i += GV_THREADS * 8) {
-        const uint4 u = *reinterpret_cast<const uint4*>(job.x + i);
-        float* d = xs + i;
-        d[0] = bf16_lo(u.x); d[1] = bf16_hi(u.x); d[2] = bf16_lo(u.y); d[3] = bf16_hi(u.y);
-        d[4] = bf16_lo(u.z); d[5] = bf16_hi(u.z); d[6] = bf16_lo(u.w); d[7] = bf16_hi(u.w);
-    }
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kchunks = K / 8;
-    const int row0 = ((int)blockIdx.x - job.wg_begin) * GV_ROWS_PER_WG + wave * (GV_ROWS_PER_WG / 4);   // 8 rows per wave
-    if (kchunks >= 64) {
-        // long rows: the whole wave walks a row; 4 rows at a time keep four 16-byte loads per lane in flight
-        for (int rb = 0; rb < GV_ROWS_PER_WG / 4; rb += 4) {
-            float acc[4][GV_MAX_B];
+    if (kchunks >= GV_LONG_KCHUNKS) {
+        constexpr int R = GV_LONG_ROWS_PER_WG / 4, U = 4;
+        const int row0 = ((int)blockIdx.x - job.wg_begin) * GV_LONG_ROWS_PER_WG + wave * R;
+        float acc[R][GV_MAX_B];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int b = 0; b < GV_MAX_B; ++b) acc[i][b] = 0.f;
-            for (int c = lane; c < kchunks; c += 64) {
-                uint4 u[4];
+            for (int b = 0; b < GV_MAX_B; ++b) acc[r][b] = 0.f;
+        for (int c0 = lane; c0 < kchunks; c0 += 64 * U) {
+            uint4 u[R][U];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int n = row0 + rb + i;
-                    u[i] = n < N ? *reinterpret_cast<const uint4*>(job.W + (size_t)n * K + c * 8) : make_uint4(0, 0, 0, 0);
+            for (int q = 0; q < U; ++q)
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int n = row0 + r, c = c0 + 64 * q;
+                    u[r][q] = (n < N && c < kchunks) ? *reinterpret_cast<const uint4*>(job.W + (size_t)n * K + c * 8) : make_uint4(0, 0, 0, 0);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float wv[8] = {bf16_lo(u[i].x), bf16_hi(u[i].x), bf16_lo(u[i].y), bf16_hi(u[i].y),
-                                         bf16_lo(u[i].z), bf16_hi(u[i].z), bf16_lo(u[i].w), bf16_hi(u[i].w)};
+            for (int q = 0; q < U; ++q) {
+                const int c = c0 + 64 * q;
+                if (c < kchunks) {
+                    float wv[R][8];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) unpack8(u[r][q], wv[r]);
 #pragma unroll
                     for (int b = 0; b < GV_MAX_B; ++b) {
                         if (b < B) {
-                            const float4 x0 = *reinterpret_cast<const float4*>(xs + b * K + c * 8);
-                            const float4 x1 = *reinterpret_cast<const float4*>(xs + b * K + c * 8 + 4);
-                            acc[i][b] += wv[0] * x0.x + wv[1] * x0.y + wv[2] * x0.z + wv[3] * x0.w
-                                       + wv[4] * x1.x + wv[5] * x1.y + wv[6] * x1.z + wv[7] * x1.w;
+                            float xv[8];
+                            unpack8(*reinterpret_cast<const uint4*>(job.x + (size_t)b * K + c * 8), xv);
+#pragma unroll
+                            for (int r = 0; r < R; ++r)
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) acc[r][b] = fmaf(wv[r][e], xv[e], acc[r][b]);
                         }
                     }
                 }
             }
+        }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = row0 + rb + i;
+        for (int r = 0; r < R; ++r) {
+            const int n = row0 + r;
 #pragma unroll
-                for (int b = 0; b < GV_MAX_B; ++b) {
-                    if (b < B) {
-                        float v = group_sum<6>(acc[i][b]);
-                        if (lane == 0 && n < N) {
-                            v = apply_act(v, job.act);
-                            if (job.res) v += bf16_to_f32(job.res[(size_t)b * N + n]);
-                            job.y[(size_t)b * N + n] = (uint16_t)f32_to_bf16_bits(v);
-                        }
+            for (int b = 0; b < GV_MAX_B; ++b) {
+                if (b < B) {
+                    float v = group_sum<6>(acc[r][b]);
+                    if (lane == 0 && n < N) {
+                        v = apply_act(v, job.act);
+                        if (job.res) v += bf16_to_f32(job.res[(size_t)b * N + n]);
+                        job.y[(size_t)b * N + n] = (uint16_t)f32_to_bf16_bits(v);
                     }
                 }
             }
         }
     } else {
         // short rows (LoRA up-projections, K = 64..256): a group of G lanes per row, 64/G rows at a time
+        for (int i = threadIdx.x * 8; i < B * K; i += GV_THREADS * 8) unpack8(*reinterpret_cast<const uint4*>(job.x + i), xs + i);
+        __syncthreads();
+        const int row0 = ((int)blockIdx.x - job.wg_begin) * GV_ROWS_PER_WG + wave * (GV_ROWS_PER_WG / 4);   // 8 rows per wave
         int G = 32;
         while (G > kchunks) G >>= 1;
         const int rows_at_once = 64 / G, sub = lane / G, gl = lane % G;
@@ -150,11 +163,12 @@ extern "C" int vrwkv_gemv_multi_bf16(int n_jobs, int B, const void* const* W, co
         if ((reinterpret_cast<uintptr_t>(W[j]) | reinterpret_cast<uintptr_t>(x[j])) & 15u) return VRWKV_EALIGN;
         a.job[j] = GemvJob{(const uint16_t*)W[j], (const uint16_t*)x[j], res ? (const uint16_t*)res[j] : nullptr, (uint16_t*)y[j],
                            N[j], K[j], act[j], wg};
-        wg += (N[j] + GV_ROWS_PER_WG - 1) / GV_ROWS_PER_WG;
-        kmax = K[j] > kmax ? K[j] : kmax;
+        const bool long_rows = K[j] / 8 >= GV_LONG_KCHUNKS;
+        const int rows = long_rows ? GV_LONG_ROWS_PER_WG : GV_ROWS_PER_WG;
+        wg += (N[j] + rows - 1) / rows;
+        if (!long_rows) kmax = K[j] > kmax ? K[j] : kmax;
     }
     const size_t lds = (size_t)B * kmax * sizeof(float);
-    if (lds > 64 * 1024) return VRWKV_ESHAPE;                          // B*K <= 16384 (e.g. B = 2 at K = 8192)
     hipLaunchKernelGGL(gemv_multi_kernel, dim3((unsigned)wg), dim3(GV_THREADS), lds, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? VRWKV_OK : (int)e;

@@ -325,7 +325,7 @@ class RWKV(nn.Module):
         use_decode = False
         if getattr(self.args, "fused", False) and x.shape[1] == 1:
             from . import decode
-            use_decode = decode.supported(x) and x.shape[0] * 4 * self.args.n_embd <= 16384
+            use_decode = decode.supported(x)
         for block in self.blocks:
             if use_decode:                               # single token: batched-GEMV step (decode.py)
                 x, v_first = decode.block_decode(block, x, v_first, state)
@@ -333,6 +333,9 @@ class RWKV(nn.Module):
             else:
                 x, v_first = block(x, v_first, state)
         state.n_tokens += x.size(1)
+        if use_decode and self.head.weight.dtype == torch.bfloat16:
+            logits = decode.head_decode(self, x)
+            return (logits if last_only else logits.unsqueeze(1)), state
         if last_only:
             x = x[:, -1]
         return self.head(self.ln_out(x)), state
