@@ -101,6 +101,17 @@ int vrwkv_wkv7_forward_state_bf16(int B, int T, int H, const void* w, const void
  * act: 0 none, 1 tanh, 2 sigmoid, 3 relu^2. */
 int vrwkv_gemv_multi_bf16(int n_jobs, int B, const void* const* W, const void* const* x, const void* const* res,
                           void* const* y, const int* N, const int* K, const int* act, void* stream);
+/* Same, plus a side job: copy_dst[0..copy_elems) = copy_src (bf16 elements, copy_elems % 8 == 0), done by one workgroup. */
+int vrwkv_gemv_multi_copy_bf16(int n_jobs, int B, const void* const* W, const void* const* x, const void* const* res,
+                               void* const* y, const int* N, const int* K, const int* act, const void* copy_src,
+                               void* copy_dst, long copy_elems, void* stream);
+/* Batched GEMV with LayerNorm + token shift + lerp folded into the input (Block.forward's ln1 / ln2 followed by the
+ * lerps of src/model.py:169-173,222-223 at T = 1):  h = LayerNorm(x; ln_w, ln_b, eps),  in_j = h + (x_prev - h) mu_j,
+ * y_j = act_j(W_j in_j).  All jobs share x (B,K) and K (512 <= K <= 4096); h is also written to h_out (B,K).  x_prev is
+ * only read: the caller replaces it by h_out in a LATER launch (the side jobs above / of vrwkv_decode_tmix_head_bf16). */
+int vrwkv_gemv_ln_multi_bf16(int n_jobs, int B, int K, const void* const* W, const void* x, const void* ln_w,
+                             const void* ln_b, float eps, const void* x_prev, const void* const* mu, void* h_out,
+                             void* const* y, const int* N, const int* act, void* stream);
 
 /* Decode step, fused glue (T = 1; replaces the launch-bound chains of src/model.py:166-194,247-254 for one token).
  * ln_mix: h = LayerNorm(x) (src/model.py:250,253: ln1 / ln2), out_j = h + (x_prev - h) * mu_j for M <= 6 lerps
@@ -112,12 +123,13 @@ int vrwkv_decode_ln_mix_bf16(int B, int C, int M, const void* x, const void* ln_
  * with their activation applied, W2t_i (C,D_i) bf16 = the reference's w2, a2, g2, v2 parameters TRANSPOSED;
  * src/model.py:176,181-183), decay soft-clamp (:176), k_k normalisation, k_a, value residual (:180-187), the WKV7 step
  * of vrwkv_wkv7_step_bf16 on `state` in place, GroupNorm ln_x + r_k bonus + gate (:190-193).  r, k, v, out: (B,C) bf16
- * with C = 64 H; v_first / v0 / hid[3] / W2t[3] NULL on layer 0; D_i % 32 == 0. */
+ * with C = 64 H; v_first / v0 / hid[3] / W2t[3] NULL on layer 0; D_i % 32 == 0.  Optional side job: carry_dst = carry_src
+ * ((B,C) bf16 each; the carried token-shift row replaced by the LayerNorm row vrwkv_gemv_ln_multi_bf16 produced). */
 int vrwkv_decode_tmix_head_bf16(int B, int H, const void* r, const void* k, const void* v, const void* v_first,
                                 const void* const* hid, const void* const* W2t, const int* D,
                                 const void* w0, const void* a0, const void* v0, const void* k_k, const void* k_a,
                                 const void* r_k, const void* ln_w, const void* ln_b, float eps,
-                                float* state, void* out, void* stream);
+                                float* state, void* out, const void* carry_src, void* carry_dst, void* stream);
 
 /* WKV7 single-token step with carried state (stateful generation; the reference re-runs the whole forward per new
  * token, VisualRWKV-v7/v7.00/src/model.py:513-529).  w..a, y: (B,H,64) bf16; state: (B,H,64,64) f32, S[i][j] with

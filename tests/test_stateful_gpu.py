@@ -62,9 +62,9 @@ def test_steps_reproduce_training_forward():
     assert rel_rms(s32, s_end) < 1e-3
 
 
-def _lm(fused):
+def _lm(fused, C=256):
     from visualrwkv_amd.rwkv7 import RWKV
-    args = SimpleNamespace(n_embd=256, n_layer=3, dim_att=256, head_size_a=64, head_size_divisor=8, vocab_size=1000,
+    args = SimpleNamespace(n_embd=C, n_layer=3, dim_att=C, head_size_a=64, head_size_divisor=8, vocab_size=1000,
                            dropout=0, grad_cp=0, ctx_len=128, load_model="", fused=fused)
     torch.manual_seed(2)
     m = RWKV(args)
@@ -191,10 +191,11 @@ def test_gemv_multi_matches_torch(B):
         assert rel_rms(y.float(), ref) < 5e-3, (W.shape, act)
 
 
-def test_decode_step_path_matches_module_path():
+@pytest.mark.parametrize("C", [256, 512])                  # 512: LayerNorm folded into the GEMV launches
+def test_decode_step_path_matches_module_path(C):
     """The batched-GEMV decode step (decode.py) against the module-level stateful step on the same state."""
-    m = _lm(fused=True)
-    x = torch.randn(2, 40, 256, device="cuda", dtype=torch.bfloat16)
+    m = _lm(fused=True, C=C)
+    x = torch.randn(2, 40, C, device="cuda", dtype=torch.bfloat16)
     _, st_a = m.forward_stateful(x[:, :32], None)
     _, st_b = m.forward_stateful(x[:, :32], None)
     m.args.fused = False                                   # module-level path (plain torch glue, wkv7_step)
@@ -208,6 +209,8 @@ def test_decode_step_path_matches_module_path():
         assert rel_rms(lg.float(), ref[i].float()) < 2e-2
     for a, b in zip(st_a.S, st_b.S):
         assert rel_rms(b, a) < 2e-2
+    for a, b in zip(st_a.att_x + st_a.ffn_x, st_b.att_x + st_b.ffn_x):      # the carried token-shift rows
+        assert rel_rms(b.float(), a.float()) < 2e-2
 
 
 @pytest.mark.parametrize("B,C,M", [(1, 256, 6), (3, 2048, 1), (2, 4096, 6)])
@@ -262,3 +265,45 @@ def test_decode_tmix_head_matches_unfused_chain(B, layer):
     got = decode.tmix_head(m, r, k, v, vf if layer > 0 else None, hidden, S)
     assert rel_rms(S, S_ref) < 2e-3
     assert rel_rms(got.float(), want.float()) < 1e-2
+
+
+@pytest.mark.parametrize("B,K", [(1, 2048), (3, 512), (2, 4096)])
+def test_gemv_ln_multi_matches_torch(B, K):
+    """vrwkv_gemv_ln_multi_bf16: LayerNorm + shift + lerp folded into the GEMV input, against fp32 torch."""
+    from visualrwkv_amd import decode
+    g = torch.Generator(device="cuda").manual_seed(K + B)
+    rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    x, prev = (rn(B, K) * 2 + 3.0).bfloat16(), rn(B, K).bfloat16()        # a large row mean: the shifted-sum statistics
+    ln = torch.nn.LayerNorm(K).cuda().bfloat16()
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.2 * rn(K)); ln.bias.copy_(0.1 * rn(K))
+    jobs = [((rn(n, K) * 0.05).bfloat16(), torch.rand(1, 1, K, device="cuda", generator=g).bfloat16(), act)
+            for n, act in ((300, decode.ACT_NONE), (64, decode.ACT_TANH), (1030, decode.ACT_RELUSQ), (8, decode.ACT_SIGMOID))]
+    carried = prev.clone()
+    ys, h = decode.gemv_ln_multi(jobs, x, ln, carried)
+    assert torch.equal(carried, prev)                                        # only read by this launch
+    h_ref = torch.nn.functional.layer_norm(x.float(), (K,), ln.weight.float(), ln.bias.float(), ln.eps).bfloat16().float()
+    assert rel_rms(h.float(), h_ref) < 3e-3
+    for (W, mu, act), y in zip(jobs, ys):
+        xin = (h_ref + (prev.float() - h_ref) * mu.view(K).float()).bfloat16().float()
+        ref = xin @ W.float().t()
+        ref = [ref, torch.tanh(ref), torch.sigmoid(ref), torch.relu(ref) ** 2][act]
+        assert rel_rms(y.float(), ref) < 8e-3, (W.shape, act)
+
+
+def test_gemv_copy_side_job_and_head_carry():
+    from visualrwkv_amd import decode
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rn = lambda *s: (torch.randn(*s, device="cuda", generator=g) * 0.3).bfloat16()
+    W, x, src, dst = rn(100, 1024), rn(2, 1024), rn(2, 2048), rn(2, 2048)
+    (y,) = decode.gemv_multi_copy([(W, x, None, decode.ACT_NONE)], 2, torch.device("cuda"), src, dst)
+    assert torch.equal(dst, src)
+    assert rel_rms(y.float(), x.float() @ W.float().t()) < 5e-3
+    m = _lm(fused=True).blocks[1].att
+    r, k, v, vf = rn(2, 256), rn(2, 256), rn(2, 256), rn(2, 256)
+    hidden = [rn(2, m.w2.shape[0]), rn(2, m.a2.shape[0]), rn(2, m.g2.shape[0]), rn(2, m.v2.shape[0])]
+    S1, S2 = torch.zeros(2, 4, 64, 64, device="cuda"), torch.zeros(2, 4, 64, 64, device="cuda")
+    src, dst = rn(2, 256), rn(2, 256)
+    a = decode.tmix_head(m, r, k, v, vf, hidden, S1)
+    b = decode.tmix_head(m, r, k, v, vf, hidden, S2, carry=(src, dst))
+    assert torch.equal(a, b) and torch.equal(S1, S2) and torch.equal(dst, src)

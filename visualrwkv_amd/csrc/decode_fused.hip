@@ -137,6 +137,8 @@ struct HeadArgs {
     float eps;
     float* state;                            // (B,H,64,64) fp32, in place
     uint16_t* out;                           // (B,C)
+    const uint16_t* carry_src;               // optional side job: carry_dst[b, 64h + c] = carry_src[b, 64h + c]
+    uint16_t* carry_dst;
 };
 
 DEVFN float dot8(const uint4& a, const uint4& b) {
@@ -158,6 +160,7 @@ __global__ __launch_bounds__(TH_THREADS) void tmix_head_kernel(HeadArgs p) {
     float4 st[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) st[i] = reinterpret_cast<const float4*>(sp)[tid + i * TH_THREADS];
+    if (p.carry_src && qd == 1) p.carry_dst[cb + c] = p.carry_src[cb + c];
     const bool vres = p.v_first != nullptr;
     const int nk = vres ? 4 : 3;
     // per-channel operands (used by wave 0 only; loaded by every wave to keep the code uniform)
@@ -269,7 +272,9 @@ extern "C" int vrwkv_decode_tmix_head_bf16(int B, int H, const void* r, const vo
                                            const void* const* hid, const void* const* W2t, const int* D,
                                            const void* w0, const void* a0, const void* v0, const void* k_k, const void* k_a,
                                            const void* r_k, const void* ln_w, const void* ln_b, float eps,
-                                           float* state, void* out, void* stream) {
+                                           float* state, void* out, const void* carry_src, void* carry_dst,
+                                           void* stream) {
+    if ((carry_src == nullptr) != (carry_dst == nullptr)) return VRWKV_EINVAL;
     if (B <= 0 || H <= 0 || !r || !k || !v || !hid || !W2t || !D || !w0 || !a0 || !k_k || !k_a || !r_k || !ln_w || !ln_b ||
         !state || !out) return VRWKV_EINVAL;
     if (v_first && !v0) return VRWKV_EINVAL;
@@ -287,6 +292,7 @@ extern "C" int vrwkv_decode_tmix_head_bf16(int B, int H, const void* r, const vo
     p.w0 = (const uint16_t*)w0; p.a0 = (const uint16_t*)a0; p.v0 = (const uint16_t*)v0; p.k_k = (const uint16_t*)k_k;
     p.k_a = (const uint16_t*)k_a; p.r_k = (const uint16_t*)r_k; p.ln_w = (const uint16_t*)ln_w; p.ln_b = (const uint16_t*)ln_b;
     p.eps = eps; p.state = state; p.out = (uint16_t*)out;
+    p.carry_src = (const uint16_t*)carry_src; p.carry_dst = (uint16_t*)carry_dst;
     hipLaunchKernelGGL(tmix_head_kernel, dim3((unsigned)(B * H)), dim3(TH_THREADS), 0, (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? VRWKV_OK : (int)e;

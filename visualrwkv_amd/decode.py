@@ -1,7 +1,8 @@
 """Single-token decode step of a Block (RWKV_Tmix_x070 + RWKV_CMix_x070, src/model.py:166-194,221-227,247-254) with
-carried state: 7 launches per layer instead of the ~25 the module-level stateful path issues.  Every nn.Linear and
+carried state: 5 launches per layer instead of the ~25 the module-level stateful path issues.  Every nn.Linear and
 first-stage LoRA product is a row of a batched GEMV launch with its activation / residual in the epilogue
-(csrc/gemv_decode.hip); LayerNorm + token shift + lerps are one kernel, and everything that is per-head -- the second
+(csrc/gemv_decode.hip); LayerNorm + token shift + lerps are folded into the GEMV that consumes them (a separate kernel
+for widths the fold does not cover), and everything that is per-head -- the second
 LoRA stage, decay, k/v/a glue, the WKV7 state step, GroupNorm + bonus + gate -- is another (csrc/decode_fused.hip).
 Inference only; first-stage LoRA factors are read through cached (N,K)-major copies (rebuilt when a parameter is
 modified in place)."""
@@ -36,6 +37,43 @@ def gemv_multi(jobs, B, device):
     return ys
 
 
+def gemv_multi_copy(jobs, B, device, copy_src, copy_dst):
+    """gemv_multi plus the side job copy_dst[:] = copy_src (the carried token-shift row, see gemv_ln_multi)."""
+    n = len(jobs)
+    ys = [torch.empty(B, W.shape[0], dtype=torch.bfloat16, device=device) for W, _, _, _ in jobs]
+    vp = ctypes.c_void_p * n
+    ip = ctypes.c_int * n
+    rc = hip_lib.load().vrwkv_gemv_multi_copy_bf16(
+        n, B, vp(*[W.data_ptr() for W, _, _, _ in jobs]), vp(*[x.data_ptr() for _, x, _, _ in jobs]),
+        vp(*[(r.data_ptr() if r is not None else 0) for _, _, r, _ in jobs]), vp(*[y.data_ptr() for y in ys]),
+        ip(*[W.shape[0] for W, _, _, _ in jobs]), ip(*[W.shape[1] for W, _, _, _ in jobs]), ip(*[a for _, _, _, a in jobs]),
+        copy_src.data_ptr(), copy_dst.data_ptr(), copy_src.numel(), _stream(device))
+    hip_lib.check(rc, "vrwkv_gemv_multi_copy_bf16")
+    return ys
+
+
+def ln_fold_supported(C):
+    return 512 <= C <= 4096 and C % 8 == 0
+
+
+def gemv_ln_multi(jobs, x, ln, x_prev):
+    """jobs: list of (W (N,K), mu (K), act); x (B,K) raw residual row.  y_j = act_j(W_j (h + (x_prev - h) mu_j)) with
+    h = LayerNorm(x), one launch.  Returns (ys, h); x_prev is NOT updated (the caller hands h to a later launch's
+    copy side job, because workgroups of this launch read x_prev until it ends)."""
+    B, K = x.shape
+    n = len(jobs)
+    ys = [torch.empty(B, W.shape[0], dtype=torch.bfloat16, device=x.device) for W, _, _ in jobs]
+    h = torch.empty_like(x)
+    vp = ctypes.c_void_p * n
+    ip = ctypes.c_int * n
+    rc = hip_lib.load().vrwkv_gemv_ln_multi_bf16(
+        n, B, K, vp(*[W.data_ptr() for W, _, _ in jobs]), x.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(), float(ln.eps),
+        x_prev.data_ptr(), vp(*[m.data_ptr() for _, m, _ in jobs]), h.data_ptr(), vp(*[y.data_ptr() for y in ys]),
+        ip(*[W.shape[0] for W, _, _ in jobs]), ip(*[a for _, _, a in jobs]), _stream(x.device))
+    hip_lib.check(rc, "vrwkv_gemv_ln_multi_bf16")
+    return ys, h
+
+
 def ln_mix(x, ln, x_prev, mus):
     """x (B,C) -> [LN(x) + (x_prev - LN(x)) * mu for mu in mus]; x_prev (B,C) is replaced by LN(x) in place."""
     B, C = x.shape
@@ -49,9 +87,10 @@ def ln_mix(x, ln, x_prev, mus):
     return outs
 
 
-def tmix_head(m, r, k, v, v_first, hidden, S):
+def tmix_head(m, r, k, v, v_first, hidden, S, carry=None):
     """Everything of RWKV_Tmix_x070.forward between the first-stage products and the output projection, for one token.
-    hidden: [tanh(xw w1), xa a1, sigmoid(xg g1)] (+ [xv v1] on layers > 0), each (B,D); S (B,H,64,64) fp32, in place."""
+    hidden: [tanh(xw w1), xa a1, sigmoid(xg g1)] (+ [xv v1] on layers > 0), each (B,D); S (B,H,64,64) fp32, in place.
+    carry: optional (src, dst) pair of (B,C) rows copied as a side job."""
     B, C = r.shape
     names = ("w2", "a2", "g2") + (("v2",) if v_first is not None else ())
     t = _transposed(m, names, "_decode_cache2")
@@ -65,7 +104,7 @@ def tmix_head(m, r, k, v, v_first, hidden, S):
         vp(*[h.data_ptr() for h in hidden]), vp(*[w.data_ptr() for w in W2]), ip(*[w.shape[1] for w in W2]),
         m.w0.data_ptr(), m.a0.data_ptr(), m.v0.data_ptr() if v_first is not None else 0, m.k_k.data_ptr(), m.k_a.data_ptr(),
         m.r_k.data_ptr(), m.ln_x.weight.data_ptr(), m.ln_x.bias.data_ptr(), float(m.ln_x.eps), S.data_ptr(), out.data_ptr(),
-        _stream(r.device))
+        carry[0].data_ptr() if carry else 0, carry[1].data_ptr() if carry else 0, _stream(r.device))
     hip_lib.check(rc, "vrwkv_decode_tmix_head_bf16")
     return out
 
@@ -99,20 +138,32 @@ def block_decode(block, x, v_first, state):
         x = block.ln0(x)
     x = x.reshape(B, C)
     t = _transposed(att, ("w1", "a1", "g1") + (("v1",) if lid > 0 else ()))
-    xr, xw, xk, xv, xa, xg = ln_mix(x, block.ln1, state.att_x[lid], [att.x_r, att.x_w, att.x_k, att.x_v, att.x_a, att.x_g])
-    jobs = [(att.receptance.weight, xr, None, ACT_NONE), (att.key.weight, xk, None, ACT_NONE), (att.value.weight, xv, None, ACT_NONE),
-            (t["w1"], xw, None, ACT_TANH), (t["a1"], xa, None, ACT_NONE), (t["g1"], xg, None, ACT_SIGMOID)]
+    fold = ln_fold_supported(C)                  # LayerNorm + shift + lerps inside the consuming GEMV launch
+    mats = [(att.receptance.weight, att.x_r, ACT_NONE), (att.key.weight, att.x_k, ACT_NONE), (att.value.weight, att.x_v, ACT_NONE),
+            (t["w1"], att.x_w, ACT_TANH), (t["a1"], att.x_a, ACT_NONE), (t["g1"], att.x_g, ACT_SIGMOID)]
     if lid > 0:
-        jobs.append((t["v1"], xv, None, ACT_NONE))
-    outs = gemv_multi(jobs, B, dev)
+        mats.append((t["v1"], att.x_v, ACT_NONE))
+    carry = None
+    if fold:
+        outs, h = gemv_ln_multi(mats, x, block.ln1, state.att_x[lid])
+        carry = (h, state.att_x[lid])
+    else:
+        ins = dict(zip(("x_r", "x_w", "x_k", "x_v", "x_a", "x_g"),
+                       ln_mix(x, block.ln1, state.att_x[lid], [att.x_r, att.x_w, att.x_k, att.x_v, att.x_a, att.x_g])))
+        names = ["x_r", "x_k", "x_v", "x_w", "x_a", "x_g", "x_v"]
+        outs = gemv_multi([(W, ins[nm], None, act) for (W, _, act), nm in zip(mats, names)], B, dev)
     r, k, v = outs[:3]
     if lid == 0:
         v_first = v.view(B, 1, C)
-    y = tmix_head(att, r, k, v, v_first.view(B, C) if lid > 0 else None, outs[3:], state.S[lid])
+    y = tmix_head(att, r, k, v, v_first.view(B, C) if lid > 0 else None, outs[3:], state.S[lid], carry)
     (x,) = gemv_multi([(att.output.weight, y, x, ACT_NONE)], B, dev)                                # x + output(y)
-    (kx,) = ln_mix(x, block.ln2, state.ffn_x[lid], [ffn.x_k])
-    (kk,) = gemv_multi([(ffn.key.weight, kx, None, ACT_RELUSQ)], B, dev)
-    (x2,) = gemv_multi([(ffn.value.weight, kk, x, ACT_NONE)], B, dev)                                # x + value(relu(key)^2)
+    if fold:
+        (kk,), h = gemv_ln_multi([(ffn.key.weight, ffn.x_k, ACT_RELUSQ)], x, block.ln2, state.ffn_x[lid])
+        (x2,) = gemv_multi_copy([(ffn.value.weight, kk, x, ACT_NONE)], B, dev, h, state.ffn_x[lid])
+    else:
+        (kx,) = ln_mix(x, block.ln2, state.ffn_x[lid], [ffn.x_k])
+        (kk,) = gemv_multi([(ffn.key.weight, kx, None, ACT_RELUSQ)], B, dev)
+        (x2,) = gemv_multi([(ffn.value.weight, kk, x, ACT_NONE)], B, dev)                            # x + value(relu(key)^2)
     return x2.view(B, 1, C), v_first
 
 

@@ -28,7 +28,9 @@ PROTOTYPES = {
     "vrwkv_ce_bwd_bf16": (_c_int, [_c_long, _c_int] + [_c_void_p] * 6 + [_c_float] + [_c_void_p] * 2),
     "vrwkv_gemv_multi_bf16": (_c_int, [_c_int, _c_int] + [_c_void_p] * 8),
     "vrwkv_decode_ln_mix_bf16": (_c_int, [_c_int] * 3 + [_c_void_p] * 3 + [_c_float] + [_c_void_p] * 4),
-    "vrwkv_decode_tmix_head_bf16": (_c_int, [_c_int] * 2 + [_c_void_p] * 15 + [_c_float] + [_c_void_p] * 3),
+    "vrwkv_decode_tmix_head_bf16": (_c_int, [_c_int] * 2 + [_c_void_p] * 15 + [_c_float] + [_c_void_p] * 5),
+    "vrwkv_gemv_multi_copy_bf16": (_c_int, [_c_int, _c_int] + [_c_void_p] * 9 + [_c_long] + [_c_void_p]),
+    "vrwkv_gemv_ln_multi_bf16": (_c_int, [_c_int] * 3 + [_c_void_p] * 4 + [_c_float] + [_c_void_p] * 7),
     "vrwkv_wkv7_forward_state_bf16": (_c_int, [_c_int] * 3 + [_c_void_p] * 12),
     "vrwkv_wkv7_step_bf16": (_c_int, [_c_int] * 2 + [_c_void_p] * 9),
     "vrwkv_wkv7_set_forward_variant": (_c_int, [_c_int]),
