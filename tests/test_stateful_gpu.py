@@ -181,7 +181,8 @@ def test_gemv_multi_matches_torch(B):
     rn = lambda *s: (torch.randn(*s, device="cuda", generator=g) * 0.3).bfloat16()
     jobs = [(rn(2048, 512), rn(B, 512), None, decode.ACT_NONE), (rn(96, 512), rn(B, 512), None, decode.ACT_TANH),
             (rn(512, 96), rn(B, 96), rn(B, 512), decode.ACT_NONE), (rn(70, 64), rn(B, 64), None, decode.ACT_SIGMOID),
-            (rn(1000, 2048), rn(B, 2048), None, decode.ACT_RELUSQ), (rn(33, 8), rn(B, 8), None, decode.ACT_NONE)]
+            (rn(1000, 2048), rn(B, 2048), None, decode.ACT_RELUSQ), (rn(33, 8), rn(B, 8), None, decode.ACT_NONE),
+            (rn(301, 8192), rn(B, 8192), rn(B, 301), decode.ACT_NONE)]             # rows split over the waves
     ys = decode.gemv_multi(jobs, B, torch.device("cuda"))
     for (W, x, res, act), y in zip(jobs, ys):
         ref = x.float() @ W.float().t()

@@ -74,8 +74,13 @@ DEVFN uint4 pack8(const float* f) {
 
 constexpr int GV_R = GV_LONG_ROWS_PER_WG / 4, GV_U = 4;      // rows per wave, 16-byte loads per row and lane in flight
 
-DEVFN void load_batch(const GemvJob& job, int row0, int c0, uint4 (&u)[GV_R][GV_U]) {
-    const int kchunks = job.K / 8;
+// Rows longer than 2048 (the 4C -> C projection of the channel mix) are split over the workgroup's waves instead:
+// 2 rows per workgroup, wave w walks quarter w of both, partial sums meet in LDS.  Four times the workgroups, and
+// again the whole matrix is in flight at once instead of four dependent batches per wave.
+__host__ __device__ inline bool split_k(int K) { return K > 2048 && K % 32 == 0; }
+__host__ __device__ inline int long_rows_per_wg(int K) { return split_k(K) ? GV_LONG_ROWS_PER_WG / 4 : GV_LONG_ROWS_PER_WG; }
+
+DEVFN void load_batch(const GemvJob& job, int row0, int c0, int kchunks, uint4 (&u)[GV_R][GV_U]) {
 #pragma unroll
     for (int q = 0; q < GV_U; ++q)
 #pragma unroll
@@ -87,24 +92,24 @@ DEVFN void load_batch(const GemvJob& job, int row0, int c0, uint4 (&u)[GV_R][GV_
 
 // One long-row wave: rows row0, row0+1 against B input vectors; `input(b, c, xv)` yields chunk c of vector b as 8 floats.
 // `first` holds the weights of the first batch (c0 = lane), loaded by the caller before whatever it had to wait for.
+// The walk covers chunks [c_begin, kchunks); acc holds per-lane partial sums.
 template <int BB, typename F>
-DEVFN void long_rows(const GemvJob& job, int B, int row0, int lane, uint4 (&first)[GV_R][GV_U], F&& input) {
+DEVFN void long_rows_acc(const GemvJob& job, int B, int row0, int lane, int c_begin, int kchunks, uint4 (&first)[GV_R][GV_U],
+                         float (&acc)[GV_R][BB], F&& input) {
     constexpr int R = GV_R, U = GV_U;
-    const int K = job.K, N = job.N, kchunks = K / 8;
-    float acc[R][BB];
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int b = 0; b < BB; ++b) acc[r][b] = 0.f;
-    for (int c0 = lane; c0 < kchunks; c0 += 64 * U) {
+    for (int c0 = c_begin + lane; c0 < kchunks; c0 += 64 * U) {
         uint4 u[R][U];
-        if (c0 == lane) {
+        if (c0 == c_begin + lane) {
 #pragma unroll
             for (int q = 0; q < U; ++q)
 #pragma unroll
                 for (int r = 0; r < R; ++r) u[r][q] = first[r][q];
         } else {
-            load_batch(job, row0, c0, u);
+            load_batch(job, row0, c0, kchunks, u);
         }
 #pragma unroll
         for (int q = 0; q < U; ++q) {
@@ -127,6 +132,14 @@ DEVFN void long_rows(const GemvJob& job, int B, int row0, int lane, uint4 (&firs
             }
         }
     }
+}
+
+template <int BB, typename F>
+DEVFN void long_rows(const GemvJob& job, int B, int row0, int lane, uint4 (&first)[GV_R][GV_U], F&& input) {
+    constexpr int R = GV_R;
+    const int N = job.N;
+    float acc[R][BB];
+    long_rows_acc<BB>(job, B, row0, lane, 0, job.K / 8, first, acc, input);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int n = row0 + r;
@@ -159,10 +172,35 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_multi_kernel(GemvArgs a) {
     const int kchunks = K / 8;
     if (a.copy_vec && blockIdx.x == 0)
         for (long i = threadIdx.x; i < a.copy_vec; i += GV_THREADS) a.copy_dst[i] = a.copy_src[i];
-    if (kchunks >= GV_LONG_KCHUNKS) {
+    if (split_k(K)) {
+        __shared__ float part[4][GV_R][GV_MAX_B];
+        const int row0 = ((int)blockIdx.x - job.wg_begin) * GV_R, kq = kchunks / 4;
+        uint4 first[GV_R][GV_U];
+        load_batch(job, row0, wave * kq + lane, (wave + 1) * kq, first);
+        float acc[GV_R][GV_MAX_B];
+        long_rows_acc<GV_MAX_B>(job, B, row0, lane, wave * kq, (wave + 1) * kq, first, acc, [&](int b, int c, float* xv) {
+            unpack8(*reinterpret_cast<const uint4*>(job.x + (size_t)b * K + c * 8), xv);
+        });
+#pragma unroll
+        for (int r = 0; r < GV_R; ++r)
+#pragma unroll
+            for (int b = 0; b < GV_MAX_B; ++b) {
+                const float v = b < B ? group_sum<6>(acc[r][b]) : 0.f;
+                if (lane == 0) part[wave][r][b] = v;
+            }
+        __syncthreads();
+        if (threadIdx.x < GV_R * GV_MAX_B) {
+            const int r = threadIdx.x / GV_MAX_B, b = threadIdx.x % GV_MAX_B, n = row0 + r;
+            if (b < B && n < N) {
+                float v = apply_act(part[0][r][b] + part[1][r][b] + part[2][r][b] + part[3][r][b], job.act);
+                if (job.res) v += bf16_to_f32(job.res[(size_t)b * N + n]);
+                job.y[(size_t)b * N + n] = (uint16_t)f32_to_bf16_bits(v);
+            }
+        }
+    } else if (kchunks >= GV_LONG_KCHUNKS) {
         const int row0 = ((int)blockIdx.x - job.wg_begin) * GV_LONG_ROWS_PER_WG + wave * GV_R;
         uint4 first[GV_R][GV_U];
-        load_batch(job, row0, lane, first);
+        load_batch(job, row0, lane, kchunks, first);
         long_rows<GV_MAX_B>(job, B, row0, lane, first, [&](int b, int c, float* xv) {
             unpack8(*reinterpret_cast<const uint4*>(job.x + (size_t)b * K + c * 8), xv);
         });
@@ -220,7 +258,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_ln_kernel(GemvArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row0 = ((int)blockIdx.x - job.wg_begin) * GV_LONG_ROWS_PER_WG + wave * GV_R;
     uint4 first[GV_R][GV_U];
-    load_batch(job, row0, lane, first);                  // the weight stream starts before the prologue's round trip
+    load_batch(job, row0, lane, kchunks, first);         // the weight stream starts before the prologue's round trip
     const uint4 zero = make_uint4(0, 0, 0, 0);
     uint4 xr[CH][BB], pr[CH][BB], lwr[CH], lbr[CH], mur[CH];
     float x0[BB];
@@ -310,7 +348,7 @@ int launch(int n_jobs, int B, const void* const* W, const void* const* x, const 
         }
         a.job[j] = GemvJob{(const uint16_t*)W[j], (const uint16_t*)x[j], res ? (const uint16_t*)res[j] : nullptr,
                            ln ? (const uint16_t*)mu[j] : nullptr, (uint16_t*)y[j], N[j], K[j], act[j], wg};
-        const int rows = long_rows ? GV_LONG_ROWS_PER_WG : GV_ROWS_PER_WG;
+        const int rows = ln ? GV_LONG_ROWS_PER_WG : long_rows ? long_rows_per_wg(K[j]) : GV_ROWS_PER_WG;
         wg += (N[j] + rows - 1) / rows;
         if (!long_rows) kmax = K[j] > kmax ? K[j] : kmax;
     }
