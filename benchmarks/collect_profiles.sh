@@ -15,4 +15,11 @@ VRWKV_FORCE_COLLECTIVES=1 timeout 300 python -m torch.distributed.run --nnodes=1
     bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | grep -v amdgpu.ids | tail -1 > $O/bench_rccl_1rank.json
 python benchmarks/wkv7_phases.py 8 2>&1 | tail -1 > $O/wkv7_phases_b8.json
 python benchmarks/wkv7_micro.py --B 8 16 32 --iters 20 2>&1 | grep -v amdgpu > $O/wkv7_micro.jsonl
-cat $O/pytest_gpu.txt; cut -c1-600 $O/bench.json
+# stateful generation: decode step (B = 1, 4), per-kernel breakdown of the captured step, prompt ingestion
+python benchmarks/decode_micro.py 64 1 2>&1 | grep -v amdgpu | tail -1 > $O/decode_micro.jsonl
+python benchmarks/decode_micro.py 64 4 2>&1 | grep -v amdgpu | tail -1 >> $O/decode_micro.jsonl
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $O/decprof -o dec -- python $R/benchmarks/decode_micro.py 64 > $O/decprof.log 2>&1)
+python benchmarks/decode_profile.py $O/decprof/dec_results.db 4000 > $O/decode_kernels.txt 2>&1; rm -rf $O/decprof
+python benchmarks/prefill_micro.py 2>&1 | grep -v amdgpu > $O/prefill_micro.jsonl
+python benchmarks/wkv6_micro.py 2>&1 | grep -v amdgpu > $O/wkv6_micro.jsonl
+cat $O/pytest_gpu.txt; cut -c1-600 $O/bench.json; cat $O/decode_micro.jsonl

@@ -308,3 +308,24 @@ def test_gemv_copy_side_job_and_head_carry():
     a = decode.tmix_head(m, r, k, v, vf, hidden, S1)
     b = decode.tmix_head(m, r, k, v, vf, hidden, S2, carry=(src, dst))
     assert torch.equal(a, b) and torch.equal(S1, S2) and torch.equal(dst, src)
+
+
+def test_decoder_for_reuses_the_captured_graph_across_prompts():
+    m = _lm(fused=True)
+    x = torch.randn(1, 48, 256, device="cuda", dtype=torch.bfloat16)
+    _, st1 = m.forward_stateful(x[:, :16], None)
+    d1 = m.decoder_for(st1)
+    for t in range(16, 20):
+        d1(x[:, t:t + 1])
+    _, st2 = m.forward_stateful(x[:, 16:48].flip(1).contiguous()[:, :32], None)         # another prompt
+    _, ref = m.forward_stateful(x[:, 16:48].flip(1).contiguous()[:, :32], None)
+    d2 = m.decoder_for(st2)
+    assert d2 is d1 and d2.state is st1 and d2.state.n_tokens == 32
+    for t in range(3):
+        tok = x[:, t:t + 1]
+        want, ref = m.forward_stateful(tok, ref, last_only=True)
+        got = d2(tok)
+        assert rel_rms(got.float(), want.float()) < 1e-3
+    with torch.no_grad():
+        m.blocks[0].att.w0.add_(0.01)                      # parameters changed in place: a new capture
+    assert m.decoder_for(st2) is not d1

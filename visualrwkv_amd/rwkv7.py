@@ -346,6 +346,21 @@ class RWKV(nn.Module):
         advanced in place by every call, exactly as `forward_stateful(x_emb, state, last_only=True)` would."""
         return GraphDecoder(self, state)
 
+    def decoder_for(self, state):
+        """`make_decoder` with the captured graph re-used across prompts: one capture per (batch size, device, parameter
+        versions); later calls copy `state` into the graph's own state tensors.  The returned decoder advances ITS
+        state (`decoder.state`), not the argument."""
+        S0 = state.S[0]
+        key = (S0.shape[0], S0.device, sum(p._version for p in self.parameters()))
+        cache = self.__dict__.setdefault("_decoders", {})
+        dec = cache.get(key)
+        if dec is None:
+            cache.clear()                                 # parameters changed (or first use): stale graphs go
+            dec = cache[key] = GraphDecoder(self, state)
+        elif dec.state is not state:
+            dec.load_state(state)
+        return dec
+
 
 class GraphDecoder:
     def __init__(self, rwkv: "RWKV", state: RWKV7State):
@@ -367,6 +382,14 @@ class GraphDecoder:
         for dst, src in zip(state.att_x + state.ffn_x + state.S, keep):
             dst.copy_(src)
         state.fresh, state.n_tokens = fresh, n_tok
+
+    @torch.no_grad()
+    def load_state(self, other: RWKV7State):
+        """Continue from another prompt's state: copied into the tensors the graph was captured on."""
+        mine = self.state
+        for dst, src in zip(mine.att_x + mine.ffn_x + mine.S, other.att_x + other.ffn_x + other.S):
+            dst.copy_(src)
+        mine.fresh, mine.n_tokens = list(other.fresh), other.n_tokens
 
     @torch.no_grad()
     def __call__(self, x_emb):

@@ -159,7 +159,7 @@ class VisualRWKV(nn.Module):
 
     @torch.no_grad()
     def generate_stateful(self, input_ids, images, do_sample, temperature, top_p, max_new_tokens, stop_token_idx,
-                          use_graph=False):
+                          use_graph=None):
         """`generate` with the recurrent state carried between tokens: one prefill over the prompt, then one
         single-token step per new token (O(1) per token instead of re-running the whole sequence).
         The prompt is left-padded once, like `RWKV.forward` pads it (src/model.py:301-307), so the first token
@@ -174,7 +174,10 @@ class VisualRWKV(nn.Module):
         rem = x.size(1) % CHUNK_LEN
         x = self.rwkv.pad_left(x, CHUNK_LEN - rem if rem else 0)
         logits, state = self.rwkv.forward_stateful(x, None, last_only=True)
-        decoder = self.rwkv.make_decoder(state) if use_graph and x.is_cuda else None
+        if use_graph is None:                            # captured step where the batched-GEMV decode path applies
+            use_graph = (x.is_cuda and bool(getattr(self.args, "fused", False)) and x.dtype == torch.bfloat16 and x.size(0) <= 4
+                         and max_new_tokens >= 8)
+        decoder = self.rwkv.decoder_for(state) if use_graph and x.is_cuda else None     # one capture per batch size, re-used
         toks, lgs, prs = [], [], []
         for _ in range(max_new_tokens):
             nxt = torch.argmax(logits, dim=-1, keepdim=True)
