@@ -58,6 +58,25 @@ def synthetic_batch(B, ctx_len, n_img, towers, device, seed):
     return {"input_ids": ids, "labels": labels, "images": images, "sample_id": [str(i) for i in range(B)]}
 
 
+def stream_copy_gbps(dev, nbytes=2 << 30, iters=10):
+    """HBM GB/s (read + write) of the library's streaming-copy kernel on `nbytes`, HIP events on the launch stream."""
+    from visualrwkv_amd import hip_lib
+    lib = hip_lib.load()
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 255)
+    dst = torch.empty_like(src)
+    st = torch.cuda.current_stream(dev)
+    run = lambda: hip_lib.check(lib.vrwkv_stream_copy(src.data_ptr(), dst.data_ptr(), nbytes, st.cuda_stream), "vrwkv_stream_copy")
+    run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        run()
+    e1.record(st)
+    e1.synchronize()
+    assert torch.equal(dst[:4096], src[:4096]) and torch.equal(dst[-4096:], src[-4096:])
+    return 2 * nbytes * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def cpu_baseline(n_embd, T):
     """CPU leg: one RWKV-7 block (time-mix incl. the WKV7 C oracle + channel-mix) forward+backward in fp32 on
     the host cores, B=1 at the bench sequence length; reported as tokens/s for a 24-layer stack of such
@@ -195,6 +214,9 @@ def main():
                 msf = sum(x for x, _ in kinds["fwd"]) / len(kinds["fwd"])
                 out["roofline"]["fwd_kernel"] = {"kernel": "wkv7c::fwd_kernel", "avg_ms": msf,
                                                  "achieved": elems * FWD_B / msf / 1e6, "frac": elems * FWD_B / msf / 1e6 / HBM_PEAK_GBPS}
+            copy = stream_copy_gbps(dev)                  # what a plain copy reaches on this box
+            out["roofline"]["stream_copy_GBps"] = copy
+            out["roofline"]["frac_of_stream_copy"] = ach / copy
             pmc = os.path.join(ROOT, "profiles", "wkv7_pmc.json")
             if os.path.exists(pmc):
                 rec = json.load(open(pmc)).get(f"bwd_B{a.micro_bsz}_T{a.ctx_len}_H{args.n_embd // 64}")

@@ -25,9 +25,11 @@ def main():
     prompt = torch.randn(B, 2624, 2048, device="cuda", dtype=torch.bfloat16)
     res = {"batch": B}
     with torch.no_grad():
+        m.forward_stateful(prompt, None, last_only=True)               # cold: library initialisation, kernel loading
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        logits, st = m.forward_stateful(prompt, None, last_only=True)
-        torch.cuda.synchronize(); res["prefill_2624_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+        for _ in range(3):
+            logits, st = m.forward_stateful(prompt, None, last_only=True)
+        torch.cuda.synchronize(); res["prefill_2624_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 2)
         for mode in ("eager", "graph"):
             _, st = m.forward_stateful(prompt[:, :64], None, last_only=True)
             dec = m.make_decoder(st) if mode == "graph" else None

@@ -217,6 +217,10 @@ int vrwkv_wkv7_profile_bf16(int backward, int B, int T, int H, const void* w, co
                             void* dw, void* dq, void* dk, void* dv, void* dz, void* da,
                             unsigned long long* dbg, void* stream);
 
+/* Streaming copy dst = src (bytes % 16 == 0): the on-box copy ceiling the WKV roofline fraction is also reported
+ * against.  Moves 2 * bytes of HBM traffic. */
+int vrwkv_stream_copy(const void* src, void* dst, long bytes, void* stream);
+
 /* Hardware probe for the GPU tests (MFMA lane maps, cross-lane primitives); one wave.
  * which: 0 = 16x16x4 f32, 1 = 32x32x2 f32, 2 = 16x16x32 bf16, 3 = 32x32x16 bf16 (d = a*b, row-major
  * f32 operands), 4 = cross-lane primitives (a: 64 floats, d: 896 floats). */

@@ -215,3 +215,15 @@ def test_fused_rejects_wrong_inputs():
     x = torch.randn(1, 4, 128, device="cuda")          # fp32: must raise, not fall back
     with pytest.raises(ValueError):
         fused.relu_sq(x)
+
+
+def test_stream_copy_moves_every_byte():
+    """vrwkv_stream_copy (the on-box copy ceiling of bench.py's roofline): exact copy, ragged tail of the tile loop."""
+    from visualrwkv_amd import hip_lib
+    lib = hip_lib.load()
+    for nbytes in (16, 32 * 1024 + 48, 5 * 1024 * 1024 + 16):
+        src = torch.randint(0, 255, (nbytes,), dtype=torch.uint8, device="cuda")
+        dst = torch.zeros_like(src)
+        hip_lib.check(lib.vrwkv_stream_copy(src.data_ptr(), dst.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream), "copy")
+        assert torch.equal(dst, src)
+    assert lib.vrwkv_stream_copy(src.data_ptr(), dst.data_ptr(), 24, None) != 0        # not a multiple of 16

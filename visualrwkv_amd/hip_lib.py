@@ -51,6 +51,7 @@ PROTOTYPES = {
     "vrwkv_adamw_step_bf16": (_c_int, [ctypes.c_long] + [_c_void_p] * 5 + [ctypes.c_float] * 5 + [_c_int, ctypes.c_float, ctypes.c_long, ctypes.c_long, _c_void_p]),
     "vrwkv_sqnorm_bf16": (_c_int, [ctypes.c_long, _c_void_p, _c_void_p, _c_void_p]),
     "vrwkv_wkv7_profile_bf16": (_c_int, [_c_int] * 4 + [_c_void_p] * 18),
+    "vrwkv_stream_copy": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p]),
     "vrwkv_debug_probe": (_c_int, [_c_int] + [_c_void_p] * 4),
 }
 
