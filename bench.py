@@ -189,7 +189,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "train tokens/sec/node VisualRWKV-7 1B5 bf16", "value": tokens / dt, "unit": "tokens/s",
+            "metric": f"train tokens/sec/node VisualRWKV-7 {a.model.upper()} bf16", "value": tokens / dt, "unit": "tokens/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"VisualRWKV-7 {a.model} + {'+'.join(towers)} ViT, {a.img_tokens} img + {a.ctx_len - a.img_tokens} text tokens, "
