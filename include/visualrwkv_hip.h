@@ -217,6 +217,15 @@ int vrwkv_wkv7_profile_bf16(int backward, int B, int T, int H, const void* w, co
                             void* dw, void* dq, void* dk, void* dv, void* dz, void* da,
                             unsigned long long* dbg, void* stream);
 
+/* Weight gradient of a skinny projection, out = Wide^T Narrow: Wide (M,Nw) and Narrow (M,D) bf16 row-major, out bf16
+ * (Nw,D), or (D,Nw) with transposed != 0.  These are the gradients of the LoRA factors of RWKV_Tmix_x070
+ * (VisualRWKV-v7/v7.00/src/model.py:176,181-183; dW1 = x^T dH: Wide = x; dW2 = h^T dOut: Wide = dOut, transposed) that
+ * autograd computes with torch.mm in the reference.  Nw % 128 == 0, D in {32,64,96,128,160,256};
+ * ws: vrwkv_wgrad_skinny_ws_floats(M,Nw,D) floats of scratch (-1: unsupported shape). */
+long vrwkv_wgrad_skinny_ws_floats(long M, int Nw, int D);
+int vrwkv_wgrad_skinny_bf16(long M, int Nw, int D, const void* wide, const void* narrow, void* out, int transposed,
+                            float* ws, void* stream);
+
 /* Streaming copy dst = src (bytes % 16 == 0): the on-box copy ceiling the WKV roofline fraction is also reported
  * against.  Moves 2 * bytes of HBM traffic. */
 int vrwkv_stream_copy(const void* src, void* dst, long bytes, void* stream);

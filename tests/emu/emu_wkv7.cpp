@@ -80,3 +80,16 @@ int emu_wkv6_backward(int B, int T, int H, const void* r, const void* k, const v
 }
 
 }  // extern "C"
+
+#include <lora_wgrad.h>
+extern "C" int emu_wgrad_skinny(long M, int Nw, int D, int S, const void* wide, const void* narrow, float* part, void* out, int transposed) {
+    const lwg::Args a{M, Nw, D, (const uint16_t*)wide, (const uint16_t*)narrow, part};
+    const dim3 grid((unsigned)(Nw / lwg::CT * (D == 64 ? 2 : 1)), (unsigned)S);
+    if (D == 32) emu::launch(grid, dim3(256), [&] { lwg::wgrad_kernel<2>(a); });
+    else if (D == 64) emu::launch(grid, dim3(256), [&] { lwg::wgrad_kernel<2>(a); });      // two column groups of 32
+    else if (D == 96) emu::launch(grid, dim3(256), [&] { lwg::wgrad_kernel<6>(a); });
+    else return -1;
+    const long n = (long)Nw * D;
+    emu::launch(dim3((unsigned)((n + 255) / 256)), dim3(256), [&] { lwg::reduce_kernel(part, S, Nw, D, transposed, (uint16_t*)out); });
+    return 0;
+}

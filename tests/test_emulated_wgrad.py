@@ -1,0 +1,25 @@
+"""The skinny weight-gradient kernel (csrc/lora_wgrad.h: transposing LDS reads feeding the MFMA, two register stages,
+M-slices + reduction) run lane-exactly on the host emulator against an fp64 product."""
+import ctypes
+
+import pytest
+import torch
+
+
+def P(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+@pytest.mark.parametrize("M,Nw,D,S,transposed", [(32, 128, 32, 1, 0), (75, 128, 96, 2, 0), (200, 256, 32, 3, 1), (161, 128, 96, 5, 1), (70, 256, 64, 2, 0)])
+def test_wgrad_skinny(emu_lib, M, Nw, D, S, transposed):
+    g = torch.Generator().manual_seed(M + D)
+    wide = torch.randn(M, Nw, generator=g).bfloat16()
+    narrow = torch.randn(M, D, generator=g).bfloat16()
+    part = torch.full((S, Nw, D), float("nan"))
+    out = torch.zeros((D, Nw) if transposed else (Nw, D), dtype=torch.bfloat16)
+    emu_lib.emu_wgrad_skinny.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int]
+    assert emu_lib.emu_wgrad_skinny(M, Nw, D, S, P(wide), P(narrow), P(part), P(out), transposed) == 0
+    ref = wide.double().t() @ narrow.double()
+    assert torch.allclose(part.sum(0).double(), ref, rtol=1e-5, atol=1e-4)          # fp32 accumulation of exact bf16 products
+    want = (ref.t() if transposed else ref).float().bfloat16()
+    assert (out.float() - want.float()).abs().max() <= 2 * want.float().abs().max() * 2 ** -8

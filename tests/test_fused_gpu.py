@@ -227,3 +227,38 @@ def test_stream_copy_moves_every_byte():
         hip_lib.check(lib.vrwkv_stream_copy(src.data_ptr(), dst.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream), "copy")
         assert torch.equal(dst, src)
     assert lib.vrwkv_stream_copy(src.data_ptr(), dst.data_ptr(), 24, None) != 0        # not a multiple of 16
+
+
+@pytest.mark.parametrize("M,K,N", [(4096, 2048, 96), (5000, 96, 2048), (2624, 2048, 64), (3001, 256, 2048), (41984, 2048, 256),
+                                   (1000, 128, 32), (777, 160, 1024)])
+def test_wgrad_skinny_matches_torch(M, K, N):
+    """vrwkv_wgrad_skinny_bf16 (x^T dy for LoRA factors, both orientations, ragged M) against an fp32 product."""
+    from visualrwkv_amd import fused
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    dy = (torch.randn(M, N, device="cuda", generator=g) * 0.1).bfloat16()
+    assert fused.wgrad_skinny_supported(x, dy)
+    got = fused.wgrad_skinny(x, dy)
+    ref = x.float().t() @ dy.float()
+    assert got.shape == (K, N) and got.dtype == torch.bfloat16
+    err = (got.float() - ref).abs().max() / ref.abs().max()
+    assert float(err) < 6e-3, float(err)                    # one bf16 rounding of an fp32 accumulation
+
+
+def test_lora_mm_gradients_match_plain_matmul():
+    from visualrwkv_amd import fused
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(2, 640, 256, device="cuda", generator=g).bfloat16().requires_grad_()
+    w1 = (torch.randn(256, 32, device="cuda", generator=g) * 0.1).bfloat16().requires_grad_()
+    w2 = (torch.randn(32, 256, device="cuda", generator=g) * 0.1).bfloat16().requires_grad_()
+    dy = torch.randn(2, 640, 256, device="cuda", generator=g).bfloat16()
+    def run(mm):
+        for t in (x, w1, w2):
+            t.grad = None
+        y = mm(torch.tanh(mm(x, w1)), w2)
+        y.backward(dy)
+        return y.detach(), x.grad.clone(), w1.grad.clone(), w2.grad.clone()
+    a, b = run(fused.lora_mm), run(torch.matmul)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for u, v in zip(a[2:], b[2:]):
+        assert float((u.float() - v.float()).abs().max() / v.float().abs().max()) < 1e-2

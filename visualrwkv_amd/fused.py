@@ -8,6 +8,7 @@ MI355X -- anything else raises.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 import torch.nn.functional as F
@@ -40,6 +41,57 @@ def _p(t):
 def _ws(ntok, C, nvec, device):
     n = hip_lib.load().vrwkv_param_grad_ws_floats(ntok, C, nvec)
     return torch.empty(n, dtype=torch.float32, device=device)
+
+
+def wgrad_skinny_supported(x2d, dy2d):
+    K, N = x2d.shape[1], dy2d.shape[1]
+    nw, d = max(K, N), min(K, N)
+    return (x2d.is_cuda and x2d.dtype == torch.bfloat16 and dy2d.dtype == torch.bfloat16 and nw % 128 == 0
+            and d in (32, 64, 96, 128, 160, 256) and nw > d)
+
+
+def wgrad_skinny(x2d, dy2d):
+    """x2d^T dy2d for (M,K), (M,N) with one of K, N a LoRA rank: csrc/lora_wgrad.h (the library's kernels for this
+    shape -- reduction over ~42 k tokens, one operand 64-256 columns wide -- run 3-4x above the cost of reading the
+    wide operand once).  Returns (K,N) bf16."""
+    x2d, dy2d = x2d.contiguous(), dy2d.contiguous()
+    M, K = x2d.shape
+    N = dy2d.shape[1]
+    wide, narrow, transposed = (x2d, dy2d, 0) if K >= N else (dy2d, x2d, 1)
+    lib = hip_lib.load()
+    nws = lib.vrwkv_wgrad_skinny_ws_floats(M, wide.shape[1], narrow.shape[1])
+    if nws < 0:
+        raise ValueError(f"wgrad_skinny: unsupported shape ({M},{K}) x ({M},{N})")
+    ws = torch.empty(nws, dtype=torch.float32, device=x2d.device)
+    out = torch.empty(K, N, dtype=torch.bfloat16, device=x2d.device)
+    rc = lib.vrwkv_wgrad_skinny_bf16(M, wide.shape[1], narrow.shape[1], wide.data_ptr(), narrow.data_ptr(), out.data_ptr(),
+                                     transposed, ws.data_ptr(), _stream(x2d))
+    hip_lib.check(rc, "vrwkv_wgrad_skinny_bf16")
+    return out
+
+
+class _LoraMM(torch.autograd.Function):
+    """x @ w for a LoRA factor w (C x rank or rank x C): library GEMMs for the output and the input gradient, the
+    skinny weight-gradient kernel for dw (src/model.py:176,181-183 -- plain `@` in the reference)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = dy @ w.t() if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            x2d, dy2d = x.reshape(-1, x.shape[-1]), dy.reshape(-1, dy.shape[-1])
+            dw = wgrad_skinny(x2d, dy2d) if wgrad_skinny_supported(x2d, dy2d) else x2d.t() @ dy2d
+        return dx, dw
+
+
+lora_mm = _LoraMM.apply
+LORA_WGRAD = os.environ.get("VRWKV_LORA_WGRAD", "1") != "0"      # A/B switch for benchmarks: 0 = autograd's torch.mm
 
 
 class _Mix(torch.autograd.Function):
@@ -348,18 +400,19 @@ def tmix_forward(m, x, v_first):
     """RWKV_Tmix_x070.forward (src/model.py:163-195) with the glue fused; `m` is the module."""
     B, T, C = x.shape
     xr, xw, xk, xv, xa, xg = mix(x, m.x_r, m.x_w, m.x_k, m.x_v, m.x_a, m.x_g)
+    mm = lora_mm if torch.is_grad_enabled() and LORA_WGRAD else torch.matmul     # training: skinny weight-gradient kernel in the backward
     r = m.receptance(xr)
-    w = decay(torch.tanh(xw @ m.w1) @ m.w2, m.w0)
+    w = decay(mm(torch.tanh(mm(xw, m.w1)), m.w2), m.w0)
     k = m.key(xk)
     v = m.value(xv)
-    al = (xa @ m.a1) @ m.a2
-    g = torch.sigmoid(xg @ m.g1) @ m.g2
+    al = mm(mm(xa, m.a1), m.a2)
+    g = mm(torch.sigmoid(mm(xg, m.g1)), m.g2)
     if m.layer_id == 0:
         v_first = v
         k2, z, b = kva(k, None, None, None, al, m.k_k, m.k_a, m.a0, None)
         v2 = v
     else:
-        vl = (xv @ m.v1) @ m.v2
+        vl = mm(mm(xv, m.v1), m.v2)
         k2, v2, z, b = kva(k, v, v_first, vl, al, m.k_k, m.k_a, m.a0, m.v0)
     y = RUN_CUDA_RWKV7g(r, w, k2, v2, z, b)
     y = post(y, r, k2, v2, g, m.ln_x.weight, m.ln_x.bias, m.r_k, m.ln_x.eps)

@@ -51,7 +51,9 @@ PROTOTYPES = {
     "vrwkv_adamw_step_bf16": (_c_int, [ctypes.c_long] + [_c_void_p] * 5 + [ctypes.c_float] * 5 + [_c_int, ctypes.c_float, ctypes.c_long, ctypes.c_long, _c_void_p]),
     "vrwkv_sqnorm_bf16": (_c_int, [ctypes.c_long, _c_void_p, _c_void_p, _c_void_p]),
     "vrwkv_wkv7_profile_bf16": (_c_int, [_c_int] * 4 + [_c_void_p] * 18),
-    "vrwkv_stream_copy": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p]),
+    "vrwkv_wgrad_skinny_ws_floats": (_c_long, [_c_long, _c_int, _c_int]),
+    "vrwkv_wgrad_skinny_bf16": (_c_int, [_c_long, _c_int, _c_int] + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 2),
+    "vrwkv_stream_copy":(_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p]),
     "vrwkv_debug_probe": (_c_int, [_c_int] + [_c_void_p] * 4),
 }
 
