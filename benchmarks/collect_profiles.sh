@@ -22,4 +22,5 @@ python benchmarks/decode_micro.py 64 4 2>&1 | grep -v amdgpu | tail -1 >> $O/dec
 python benchmarks/decode_profile.py $O/decprof/dec_results.db 4000 > $O/decode_kernels.txt 2>&1; rm -rf $O/decprof
 python benchmarks/prefill_micro.py 2>&1 | grep -v amdgpu > $O/prefill_micro.jsonl
 python benchmarks/wkv6_micro.py 2>&1 | grep -v amdgpu > $O/wkv6_micro.jsonl
+python benchmarks/wgrad_micro.py 2>&1 | grep -v amdgpu > $O/wgrad_micro.jsonl
 cat $O/pytest_gpu.txt; cut -c1-600 $O/bench.json; cat $O/decode_micro.jsonl

@@ -1,4 +1,12 @@
-"""Host-side mirror of the reference's RWKV-6 modules (VisualRWKV-v6/v6.0/src/model.py:92-226): same class names,
+"""Host-side mirror of the reference's RWKV-6 modules (VisualRWKV-v6/v6.0/src/model.py:92-226): same def _lora_mm(x, w):
+    """x @ w for a LoRA factor; on the GPU under autograd the weight gradient runs in csrc/lora_wgrad.h (fused.lora_mm)."""
+    if x.is_cuda and torch.is_grad_enabled():
+        from .fused import lora_mm
+        return lora_mm(x, w)
+    return x @ w
+
+
+class names,
 constructor arguments, parameter names and initialisers (=> the reference's state-dict keys), forward through
 RUN_CUDA_RWKV6.  BASELINE config 4 (VisualRWKV-6 7B) runs the same Block/RWKV/VisualRWKV scaffolding around these."""
 from __future__ import annotations
@@ -57,7 +65,7 @@ class RWKV_Tmix_x060(nn.Module):
         B, T, C = x.size()
         xx = time_shift(x) - x
         xxx = x + xx * self.time_maa_x
-        xxx = torch.tanh(xxx @ self.time_maa_w1).view(B * T, 5, -1).transpose(0, 1)
+        xxx = torch.tanh(_lora_mm(xxx, self.time_maa_w1)).view(B * T, 5, -1).transpose(0, 1)
         xxx = torch.bmm(xxx, self.time_maa_w2).view(5, B, T, -1)
         mw, mk, mv, mr, mg = xxx.unbind(dim=0)
         xw = x + xx * (self.time_maa_w + mw)
@@ -69,7 +77,7 @@ class RWKV_Tmix_x060(nn.Module):
         k = self.key(xk)
         v = self.value(xv)
         g = F.silu(self.gate(xg))
-        w = self.time_decay + torch.tanh(xw @ self.time_decay_w1) @ self.time_decay_w2
+        w = self.time_decay + _lora_mm(torch.tanh(_lora_mm(xw, self.time_decay_w1)), self.time_decay_w2)
         return r, k, v, g, w
 
     def forward(self, x, wkv=None):
