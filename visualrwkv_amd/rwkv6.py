@@ -1,12 +1,4 @@
-"""Host-side mirror of the reference's RWKV-6 modules (VisualRWKV-v6/v6.0/src/model.py:92-226): same def _lora_mm(x, w):
-    """x @ w for a LoRA factor; on the GPU under autograd the weight gradient runs in csrc/lora_wgrad.h (fused.lora_mm)."""
-    if x.is_cuda and torch.is_grad_enabled():
-        from .fused import lora_mm
-        return lora_mm(x, w)
-    return x @ w
-
-
-class names,
+"""Host-side mirror of the reference's RWKV-6 modules (VisualRWKV-v6/v6.0/src/model.py:92-226): same class names,
 constructor arguments, parameter names and initialisers (=> the reference's state-dict keys), forward through
 RUN_CUDA_RWKV6.  BASELINE config 4 (VisualRWKV-6 7B) runs the same Block/RWKV/VisualRWKV scaffolding around these."""
 from __future__ import annotations
@@ -16,6 +8,14 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import wkv6 as _wkv6
+
+
+def _lora_mm(x, w):
+    """x @ w for a LoRA factor; on the GPU under autograd the weight gradient runs in csrc/lora_wgrad.h (fused.lora_mm)."""
+    if x.is_cuda and torch.is_grad_enabled():
+        from .fused import lora_mm
+        return lora_mm(x, w)
+    return x @ w
 
 
 def time_shift(x):
