@@ -90,6 +90,6 @@ extern "C" int emu_wgrad_skinny(long M, int Nw, int D, int S, const void* wide, 
     else if (D == 96) emu::launch(grid, dim3(256), [&] { lwg::wgrad_kernel<6>(a); });
     else return -1;
     const long n = (long)Nw * D;
-    emu::launch(dim3((unsigned)((n + 255) / 256)), dim3(256), [&] { lwg::reduce_kernel(part, S, Nw, D, transposed, (uint16_t*)out); });
+    emu::launch(dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), [&] { lwg::reduce_kernel(part, S, Nw, D, transposed, (uint16_t*)out); });
     return 0;
 }

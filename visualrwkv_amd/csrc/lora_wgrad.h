@@ -130,15 +130,38 @@ __global__ __launch_bounds__(256, (ND <= 6 ? 3 : 2)) void wgrad_kernel(Args p) {
                 out[(size_t)(col0 + 16 * (2 * wave + ct) + 4 * g + r) * p.D + 16 * n + c16] = acc[ct][n][r];
 }
 
-// out (bf16) = sum over the S slices; transposed: out[d][nw] instead of out[nw][d]
+// out (bf16) = sum over the S slices; transposed: out[d][nw] instead of out[nw][d].  One thread per 4 consecutive
+// elements (D % 16 == 0: they share a row), four independent partial sums so that the S loads overlap.
 __global__ __launch_bounds__(256) void reduce_kernel(const float* __restrict__ part, int S, int Nw, int D, int transposed,
                                                      uint16_t* __restrict__ out) {
-    const long n = (long)Nw * D;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = 0; k < S; ++k) s += part[(size_t)k * n + i];
-        const long o = transposed ? (i % D) * Nw + i / D : i;
-        out[o] = (uint16_t)f32_to_bf16_bits(s);
+    const long n4 = (long)Nw * D / 4;
+    const float4* p4 = reinterpret_cast<const float4*>(part);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int k = 0;
+        for (; k + 4 <= S; k += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 v = p4[(size_t)(k + u) * n4 + i];
+                acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
+            }
+        }
+        for (; k < S; ++k) {
+            const float4 v = p4[(size_t)k * n4 + i];
+            acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+        }
+        const float s[4] = {(acc[0].x + acc[1].x) + (acc[2].x + acc[3].x), (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y),
+                            (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z), (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w)};
+        const long e = 4 * i;
+        if (!transposed) {
+            *reinterpret_cast<uint2*>(out + e) = make_uint2(pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3]));
+        } else {
+            const long nw = e / D, d = e % D;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[(d + j) * Nw + nw] = (uint16_t)f32_to_bf16_bits(s[j]);
+        }
     }
 }
 

@@ -6,10 +6,11 @@
 
 namespace {
 
-// M-slices: enough workgroups for ~3 (D <= 128) or ~2 (wider accumulators) per CU of the 256
+// M-slices: ~2 workgroups per CU of the 256; more slices cost more partial-sum traffic than they hide latency
 int splits(long M, int Nw, int D) {
     const long nsteps = (M + lwg::KS - 1) / lwg::KS;
-    long s = (D <= 96 ? 768 : D <= 160 ? 512 : 256) / (Nw / lwg::CT);       // D = 256 runs two column groups per slice
+    long s = (D <= 160 ? 512 : 256) / (Nw / lwg::CT);     // measured at Nw = 2048: 32 slices (16 for D = 256, which runs
+                                                          // two column groups per slice) beat 24, 48 and 64
     if (s < 1) s = 1;
     return (int)(s < nsteps ? s : nsteps);
 }
@@ -49,7 +50,7 @@ extern "C" int vrwkv_wgrad_skinny_bf16(long M, int Nw, int D, const void* wide, 
     }
     if (e) return e;
     const long n = (long)Nw * D;
-    hipLaunchKernelGGL(lwg::reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws, S, Nw, D, transposed, (uint16_t*)out);
+    hipLaunchKernelGGL(lwg::reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, ws, S, Nw, D, transposed, (uint16_t*)out);
     hipError_t e2 = hipGetLastError();
     return e2 == hipSuccess ? VRWKV_OK : (int)e2;
 }
