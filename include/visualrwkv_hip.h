@@ -171,6 +171,10 @@ int vrwkv_mix_fwd_prev_bf16(long ntok, int T, int C, int M, const void* x, const
 long vrwkv_param_grad_ws_floats(long ntok, int C, int nvec);
 int vrwkv_mix_bwd_bf16(long ntok, int T, int C, int M, const void* x, const void* const* mu, const void* const* dout,
                        void* dx, float* dmu, float* ws, void* stream);
+/* same with a second gradient for output 3 (M == 6 only; NULL = none): x_v feeds the value projection AND the v-gate
+ * LoRA (src/model.py:178,182); the two gradients are summed in the kernel instead of by autograd's element-wise add */
+int vrwkv_mix_bwd2_bf16(long ntok, int T, int C, int M, const void* x, const void* const* mu, const void* const* dout,
+                        const void* dout3_second, void* dx, float* dmu, float* ws, void* stream);
 int vrwkv_decay_fwd_bf16(long ntok, int C, const void* h, const void* w0, void* w, void* stream);
 int vrwkv_decay_bwd_bf16(long ntok, int C, const void* h, const void* w0, const void* dw, void* dh, float* dw0, float* ws,
                          void* stream);
@@ -182,6 +186,13 @@ int vrwkv_kva_bwd_bf16(long ntok, int C, int has_vres, const void* k, const void
                        const void* dk2, const void* dv2, const void* dz, const void* db,
                        void* dk, void* dv, void* dvfirst, void* dvl, void* dal,
                        float* dparams /* 4*C: dk_k dk_a da0 dv0 */, float* ws, void* stream);
+/* same with optional second gradients of k2 and v2 (NULL = none): both feed the WKV7 op AND the bonus term of `post`
+ * (src/model.py:190,193) */
+int vrwkv_kva_bwd2_bf16(long ntok, int C, int has_vres, const void* k, const void* v, const void* vfirst, const void* vl,
+                        const void* al, const void* k_k, const void* k_a, const void* a0, const void* v0,
+                        const void* dk2, const void* dv2, const void* dz, const void* db, const void* dk2_second,
+                        const void* dv2_second, void* dk, void* dv, void* dvfirst, void* dvl, void* dal,
+                        float* dparams, float* ws, void* stream);
 int vrwkv_post_fwd_bf16(long ntok, int C, float eps, const void* y, const void* r, const void* k, const void* v,
                         const void* g, const void* ln_w, const void* ln_b, const void* r_k, void* out, void* stream);
 int vrwkv_post_bwd_bf16(long ntok, int C, float eps, const void* y, const void* r, const void* k, const void* v,

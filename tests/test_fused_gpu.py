@@ -262,3 +262,45 @@ def test_lora_mm_gradients_match_plain_matmul():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     for u, v in zip(a[2:], b[2:]):
         assert float((u.float() - v.float()).abs().max() / v.float().abs().max()) < 1e-2
+
+
+def test_aliased_outputs_sum_gradients_in_the_kernels():
+    """mix_dup3 / kva(dup=True): the aliases' gradients are summed inside mix_bwd / kva_bwd -- same result as autograd's
+    own accumulation on the un-aliased functions."""
+    from visualrwkv_amd import fused
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rn = lambda *s: (torch.randn(*s, device="cuda", generator=g) * 0.5).bfloat16()
+    B, T, C = 2, 48, 256
+    x = rn(B, T, C).requires_grad_()
+    mus = [torch.rand(1, 1, C, device="cuda", generator=g).bfloat16().requires_grad_() for _ in range(6)]
+    w = [rn(B, T, C) for _ in range(7)]
+    def grads(outs, second):
+        for t in [x] + mus:
+            t.grad = None
+        loss = sum((o.float() * wi.float()).sum() for o, wi in zip(outs, w[:6])) + (second.float() * w[6].float()).sum()
+        loss.backward()
+        return [x.grad.clone()] + [m.grad.clone() for m in mus]
+    o = fused.mix(x, *mus)
+    ref = grads(o, o[3])
+    o = fused.mix_dup3(x, *mus)
+    assert len(o) == 7 and o[6].data_ptr() == o[3].data_ptr()
+    got = grads(o[:6], o[6])
+    for a, b in zip(got, ref):
+        assert float((a.float() - b.float()).abs().max()) <= 0.02 * float(b.float().abs().max()) + 1e-3
+    # kva
+    k, v, vf, vl, al = [rn(B, T, C).requires_grad_() for _ in range(5)]
+    k_k, k_a, a0, v0 = [rn(1, 1, C).requires_grad_() for _ in range(4)]
+    leaves = [k, v, vf, vl, al, k_k, k_a, a0, v0]
+    wk = [rn(B, T, C) for _ in range(6)]
+    def kgrads(outs):
+        for t in leaves:
+            t.grad = None
+        sum((o.float() * wi.float()).sum() for o, wi in zip(outs, wk)).backward()
+        return [t.grad.clone() for t in leaves]
+    k2, v2, z, b = fused.kva(k, v, vf, vl, al, k_k, k_a, a0, v0)
+    ref = kgrads([k2, v2, z, b, k2, v2])
+    outs = fused.kva(k, v, vf, vl, al, k_k, k_a, a0, v0, True)
+    assert len(outs) == 6 and outs[4].data_ptr() == outs[0].data_ptr() and outs[5].data_ptr() == outs[1].data_ptr()
+    got = kgrads(outs)
+    for a, b in zip(got, ref):
+        assert float((a.float() - b.float()).abs().max()) <= 0.02 * float(b.float().abs().max()) + 1e-3

@@ -121,9 +121,12 @@ DEVFN V4 ld4f(const uint16_t* p) {
 DEVFN void st4f(uint16_t* p, const V4& v) {
     *reinterpret_cast<uint2*>(p) = make_uint2(cvt_pk_bf16(v.f[0], v.f[1]), cvt_pk_bf16(v.f[2], v.f[3]));
 }
-template <int M>
+// DUP3: output 3 (x_v of the time-mix) has two consumers (value projection, v-gate LoRA); their gradients arrive as
+// dout.p[3] and dout3b and are summed here instead of by a separate element-wise kernel (3 x 172 MB per layer).
+template <int M, bool DUP3>
 __global__ __launch_bounds__(512) void mix_bwd_kernel(long ntok, int T, int C, const uint16_t* __restrict__ x, Ptrs6 mu, Ptrs6 dout,
-                                                      uint16_t* __restrict__ dx, float* __restrict__ dmu) {
+                                                      const uint16_t* __restrict__ dout3b, uint16_t* __restrict__ dx,
+                                                      float* __restrict__ dmu) {
     const long lo = ntok * blockIdx.x / gridDim.x, hi = ntok * (blockIdx.x + 1) / gridDim.x;
     for (int c0 = threadIdx.x * 4; c0 < C; c0 += blockDim.x * 4) {
         V4 m[M], gm[M];
@@ -148,6 +151,11 @@ __global__ __launch_bounds__(512) void mix_bwd_kernel(long ntok, int T, int C, c
             V4 d[M];
 #pragma unroll
             for (int j = 0; j < M; ++j) d[j] = ld4f(dout.p[j] + n * C + c0);
+            if (DUP3) {
+                const V4 d2 = ld4f(dout3b + n * C + c0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[M > 3 ? 3 : 0].f[e] += d2.f[e];
+            }
             const V4 xv = ld4f(x + (inside ? n : n - 1) * C + c0);
             V4 dsum, bv;
 #pragma unroll
@@ -264,7 +272,8 @@ struct KvaBwd {
     const uint16_t *dk2, *dv2, *dz, *db;               // incoming
     uint16_t *dk, *dv, *dvfirst, *dvl, *dal;           // outgoing
     float* part;                                       // [grid][4][C] partials of dk_k dk_a da0 dv0
-};
+    const uint16_t *dk2b, *dv2b;                       // optional second gradients of k2 / v2 (two consumers: WKV7 and the
+};                                                     // bonus term of `post`), summed here instead of by autograd
 __global__ void kva_bwd_kernel(KvaBwd p) {
     const int c0 = threadIdx.x * 8, C = p.C;
     const V8 kk_p = ld8f(p.k_k + c0), ka_p = ld8f(p.k_a + c0), a0 = ld8f(p.a0 + c0);
@@ -274,7 +283,13 @@ __global__ void kva_bwd_kernel(KvaBwd p) {
     for (long n = range_lo(p.ntok), hi = range_hi(p.ntok); n < hi; ++n) {
         const long o = n * C + c0;
         const V8 k = ld8f(p.k + o), al = ld8f(p.al + o);
-        const V8 dk2 = ld8f(p.dk2 + o), dz = ld8f(p.dz + o), db = ld8f(p.db + o);
+        V8 dk2 = ld8f(p.dk2 + o);
+        const V8 dz = ld8f(p.dz + o), db = ld8f(p.db + o);
+        if (p.dk2b) {
+            const V8 t = ld8f(p.dk2b + o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dk2.f[e] += t.f[e];
+        }
         V8 a, u, kk, dkk, dk, dal;
         float ss = 0.f;
 #pragma unroll
@@ -306,7 +321,13 @@ __global__ void kva_bwd_kernel(KvaBwd p) {
         }
         st8f(p.dk + o, dk); st8f(p.dal + o, dal);
         if (p.has_vres) {
-            const V8 v = ld8f(p.v + o), vf = ld8f(p.vfirst + o), vl = ld8f(p.vl + o), dv2 = ld8f(p.dv2 + o);
+            const V8 v = ld8f(p.v + o), vf = ld8f(p.vfirst + o), vl = ld8f(p.vl + o);
+            V8 dv2 = ld8f(p.dv2 + o);
+            if (p.dv2b) {
+                const V8 t = ld8f(p.dv2b + o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dv2.f[e] += t.f[e];
+            }
             V8 dv, dvf, dvl;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -462,15 +483,23 @@ long vrwkv_param_grad_ws_floats(long ntok, int C, int nvec) { return (long)bwd_g
 
 int vrwkv_mix_bwd_bf16(long ntok, int T, int C, int M, const void* x, const void* const* mu, const void* const* dout,
                        void* dx, float* dmu, float* ws, void* stream) {
+    return vrwkv_mix_bwd2_bf16(ntok, T, C, M, x, mu, dout, nullptr, dx, dmu, ws, stream);
+}
+
+int vrwkv_mix_bwd2_bf16(long ntok, int T, int C, int M, const void* x, const void* const* mu, const void* const* dout,
+                        const void* dout3_second, void* dx, float* dmu, float* ws, void* stream) {
     if (ntok <= 0 || T <= 0 || !x || !mu || !dout || !dx || !dmu || !ws || (M != 1 && M != 6)) return VRWKV_EINVAL;
+    if (dout3_second && M != 6) return VRWKV_EINVAL;
     if (!ok_c(C) || ntok % T != 0) return VRWKV_ESHAPE;
     Ptrs6 m{}, d{};
     for (int i = 0; i < M; ++i) { m.p[i] = (const uint16_t*)mu[i]; d.p[i] = (const uint16_t*)dout[i]; if (!m.p[i] || !d.p[i]) return VRWKV_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     const int G = bwd_grid(ntok);
     const int threads = C / 4 < 512 ? C / 4 : 512;
-    if (M == 6) hipLaunchKernelGGL(mix_bwd_kernel<6>, dim3(G), dim3(threads), 0, st, ntok, T, C, (const uint16_t*)x, m, d, (uint16_t*)dx, ws);
-    else hipLaunchKernelGGL(mix_bwd_kernel<1>, dim3(G), dim3(threads), 0, st, ntok, T, C, (const uint16_t*)x, m, d, (uint16_t*)dx, ws);
+    const uint16_t* d2 = (const uint16_t*)dout3_second;
+    if (M == 6 && d2) hipLaunchKernelGGL((mix_bwd_kernel<6, true>), dim3(G), dim3(threads), 0, st, ntok, T, C, (const uint16_t*)x, m, d, d2, (uint16_t*)dx, ws);
+    else if (M == 6) hipLaunchKernelGGL((mix_bwd_kernel<6, false>), dim3(G), dim3(threads), 0, st, ntok, T, C, (const uint16_t*)x, m, d, d2, (uint16_t*)dx, ws);
+    else hipLaunchKernelGGL((mix_bwd_kernel<1, false>), dim3(G), dim3(threads), 0, st, ntok, T, C, (const uint16_t*)x, m, d, d2, (uint16_t*)dx, ws);
     colsum(G, (long)M * C, ws, dmu, st);
     return done();
 }
@@ -508,13 +537,23 @@ int vrwkv_kva_bwd_bf16(long ntok, int C, int has_vres, const void* k, const void
                        const void* dk2, const void* dv2, const void* dz, const void* db,
                        void* dk, void* dv, void* dvfirst, void* dvl, void* dal,
                        float* dparams, float* ws, void* stream) {
+    return vrwkv_kva_bwd2_bf16(ntok, C, has_vres, k, v, vfirst, vl, al, k_k, k_a, a0, v0, dk2, dv2, dz, db, nullptr, nullptr,
+                               dk, dv, dvfirst, dvl, dal, dparams, ws, stream);
+}
+int vrwkv_kva_bwd2_bf16(long ntok, int C, int has_vres, const void* k, const void* v, const void* vfirst, const void* vl, const void* al,
+                        const void* k_k, const void* k_a, const void* a0, const void* v0,
+                        const void* dk2, const void* dv2, const void* dz, const void* db, const void* dk2_second, const void* dv2_second,
+                        void* dk, void* dv, void* dvfirst, void* dvl, void* dal,
+                        float* dparams, float* ws, void* stream) {
+    if (dv2_second && !has_vres) return VRWKV_EINVAL;
     if (ntok <= 0 || !k || !al || !k_k || !k_a || !a0 || !dk2 || !dz || !db || !dk || !dal || !dparams || !ws) return VRWKV_EINVAL;
     if (has_vres && (!v || !vfirst || !vl || !v0 || !dv2 || !dv || !dvfirst || !dvl)) return VRWKV_EINVAL;
     if (!ok_c(C)) return VRWKV_ESHAPE;
     KvaBwd p{ntok, C, has_vres, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)vfirst, (const uint16_t*)vl, (const uint16_t*)al,
              (const uint16_t*)k_k, (const uint16_t*)k_a, (const uint16_t*)a0, (const uint16_t*)v0,
              (const uint16_t*)dk2, (const uint16_t*)dv2, (const uint16_t*)dz, (const uint16_t*)db,
-             (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dvfirst, (uint16_t*)dvl, (uint16_t*)dal, ws};
+             (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dvfirst, (uint16_t*)dvl, (uint16_t*)dal, ws,
+             (const uint16_t*)dk2_second, (const uint16_t*)dv2_second};
     const int G = bwd_grid(ntok);
     hipLaunchKernelGGL(kva_bwd_kernel, dim3(G), dim3(C / 8), 0, (hipStream_t)stream, p);
     colsum(G, 4L * C, ws, dparams, (hipStream_t)stream);       // dparams = [dk_k | dk_a | da0 | dv0], C floats each

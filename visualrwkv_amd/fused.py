@@ -92,6 +92,7 @@ class _LoraMM(torch.autograd.Function):
 
 lora_mm = _LoraMM.apply
 LORA_WGRAD = os.environ.get("VRWKV_LORA_WGRAD", "1") != "0"      # A/B switch for benchmarks: 0 = autograd's torch.mm
+GRAD_ALIAS = os.environ.get("VRWKV_GRAD_ALIAS", "1") != "0"      # A/B switch: 0 = autograd sums the gradients of x_v, k2, v2
 
 
 class _Mix(torch.autograd.Function):
@@ -99,6 +100,10 @@ class _Mix(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, *mus):
+        return _Mix._forward(ctx, False, x, *mus)
+
+    @staticmethod
+    def _forward(ctx, dup3, x, *mus):
         B, T, C = x.shape
         x = x.contiguous()
         mus_c = [m.reshape(C).contiguous() for m in mus]
@@ -108,6 +113,8 @@ class _Mix(torch.autograd.Function):
         hip_lib.check(rc, "vrwkv_mix_fwd_bf16")
         ctx.save_for_backward(x, *mus_c)
         ctx.mu_shapes = [m.shape for m in mus]
+        if dup3:                 # a 7th output aliasing output 3 (x_v) for its second consumer
+            outs.append(outs[3].view_as(outs[3]))
         return tuple(outs)
 
     @staticmethod
@@ -116,14 +123,25 @@ class _Mix(torch.autograd.Function):
         B, T, C = x.shape
         douts = [d.contiguous() for d in douts]
         _chk(*douts)
+        M = len(mus_c)
+        second = douts[M] if len(douts) > M else None          # gradient of the alias of output 3
         dx = torch.empty_like(x)
-        dmu = torch.empty(len(mus_c), C, dtype=torch.float32, device=x.device)
-        ws = _ws(B * T, C, len(mus_c), x.device)
-        rc = hip_lib.load().vrwkv_mix_bwd_bf16(B * T, T, C, len(mus_c), x.data_ptr(), _ptr_array(mus_c), _ptr_array(douts),
-                                               dx.data_ptr(), dmu.data_ptr(), ws.data_ptr(), _stream(x))
-        hip_lib.check(rc, "vrwkv_mix_bwd_bf16")
+        dmu = torch.empty(M, C, dtype=torch.float32, device=x.device)
+        ws = _ws(B * T, C, M, x.device)
+        rc = hip_lib.load().vrwkv_mix_bwd2_bf16(B * T, T, C, M, x.data_ptr(), _ptr_array(mus_c), _ptr_array(douts[:M]), _p(second),
+                                                dx.data_ptr(), dmu.data_ptr(), ws.data_ptr(), _stream(x))
+        hip_lib.check(rc, "vrwkv_mix_bwd2_bf16")
         dmu = dmu.to(x.dtype)
         return (dx, *[dmu[i].view(s) for i, s in enumerate(ctx.mu_shapes)])
+
+
+class _MixDup3(_Mix):
+    """`_Mix` for the time-mix of layers > 0: x_v is returned twice (the second an alias) so that the gradients of its two
+    consumers reach mix_bwd as separate inputs and are summed there, not by an element-wise kernel of autograd."""
+
+    @staticmethod
+    def forward(ctx, x, *mus):
+        return _Mix._forward(ctx, True, x, *mus)
 
 
 class _Decay(torch.autograd.Function):
@@ -158,10 +176,12 @@ class _Decay(torch.autograd.Function):
 
 
 class _Kva(torch.autograd.Function):
-    """(k, v, v_first, vl, al; k_k, k_a, a0, v0) -> (k2, v2, z, b); v/v_first/vl/v0 are None for layer 0."""
+    """(k, v, v_first, vl, al; k_k, k_a, a0, v0) -> (k2, v2, z, b); v/v_first/vl/v0 are None for layer 0.
+    dup=True appends aliases of k2 (and v2) for a second consumer: their gradients reach the backward kernel as
+    separate inputs and are summed there (autograd would run one 3 x 172 MB element-wise add per tensor and layer)."""
 
     @staticmethod
-    def forward(ctx, k, v, v_first, vl, al, k_k, k_a, a0, v0):
+    def forward(ctx, k, v, v_first, vl, al, k_k, k_a, a0, v0, dup=False):
         has = v is not None
         k, al = k.contiguous(), al.contiguous()
         C = k.shape[-1]
@@ -178,22 +198,28 @@ class _Kva(torch.autograd.Function):
                                                k2.data_ptr(), _p(v2), z.data_ptr(), b.data_ptr(), _stream(k))
         hip_lib.check(rc, "vrwkv_kva_fwd_bf16")
         ctx.has = has
+        ctx.dup = bool(dup)
         ctx.shapes = (k_k.shape, k_a.shape, a0.shape, v0.shape if has else None)
         ctx.save_for_backward(k, v, v_first, vl, al, pk, pa, p0, pv)
-        if has:
-            return k2, v2, z, b
-        return k2, z, b
+        outs = (k2, v2, z, b) if has else (k2, z, b)
+        if dup:                 # aliases for the second consumer (`post`): autograd then delivers their gradients separately
+            outs += (k2.view_as(k2), v2.view_as(v2)) if has else (k2.view_as(k2),)
+        return outs
 
     @staticmethod
     def backward(ctx, *grads):
         k, v, v_first, vl, al, pk, pa, p0, pv = ctx.saved_tensors
         has = ctx.has
+        n = 4 if has else 3
+        main, extra = [g.contiguous() for g in grads[:n]], [g.contiguous() for g in grads[n:]]
         if has:
-            dk2, dv2, dz, db = [g.contiguous() for g in grads]
+            dk2, dv2, dz, db = main
         else:
-            dk2, dz, db = [g.contiguous() for g in grads]
+            dk2, dz, db = main
             dv2 = None
-        _chk(dk2, dv2, dz, db)
+        dk2b = extra[0] if extra else None
+        dv2b = extra[1] if len(extra) > 1 else None
+        _chk(dk2, dv2, dz, db, dk2b, dv2b)
         C = k.shape[-1]
         ntok = k.numel() // C
         dk, dal = torch.empty_like(k), torch.empty_like(k)
@@ -202,15 +228,16 @@ class _Kva(torch.autograd.Function):
         dvl = torch.empty_like(k) if has else None
         pg = torch.empty(4, C, dtype=torch.float32, device=k.device)
         ws = _ws(ntok, C, 4, k.device)
-        rc = hip_lib.load().vrwkv_kva_bwd_bf16(ntok, C, int(has), k.data_ptr(), _p(v), _p(v_first), _p(vl), al.data_ptr(),
-                                               pk.data_ptr(), pa.data_ptr(), p0.data_ptr(), _p(pv),
-                                               dk2.data_ptr(), _p(dv2), dz.data_ptr(), db.data_ptr(),
-                                               dk.data_ptr(), _p(dv), _p(dvf), _p(dvl), dal.data_ptr(),
-                                               pg.data_ptr(), ws.data_ptr(), _stream(k))
-        hip_lib.check(rc, "vrwkv_kva_bwd_bf16")
+        rc = hip_lib.load().vrwkv_kva_bwd2_bf16(ntok, C, int(has), k.data_ptr(), _p(v), _p(v_first), _p(vl), al.data_ptr(),
+                                                pk.data_ptr(), pa.data_ptr(), p0.data_ptr(), _p(pv),
+                                                dk2.data_ptr(), _p(dv2), dz.data_ptr(), db.data_ptr(), _p(dk2b), _p(dv2b),
+                                                dk.data_ptr(), _p(dv), _p(dvf), _p(dvl), dal.data_ptr(),
+                                                pg.data_ptr(), ws.data_ptr(), _stream(k))
+        hip_lib.check(rc, "vrwkv_kva_bwd2_bf16")
         pgb = pg.to(k.dtype)
         s = ctx.shapes
-        return (dk, dv, dvf, dvl, dal, pgb[0].view(s[0]), pgb[1].view(s[1]), pgb[2].view(s[2]), pgb[3].view(s[3]) if has else None)
+        res = (dk, dv, dvf, dvl, dal, pgb[0].view(s[0]), pgb[1].view(s[1]), pgb[2].view(s[2]), pgb[3].view(s[3]) if has else None)
+        return res + (None,) if ctx.dup else res
 
 
 class _Post(torch.autograd.Function):
@@ -272,6 +299,7 @@ class _ReluSq(torch.autograd.Function):
 
 
 mix = _Mix.apply
+mix_dup3 = _MixDup3.apply
 decay = _Decay.apply
 kva = _Kva.apply
 post = _Post.apply
@@ -399,7 +427,12 @@ def ce_supported(logits):
 def tmix_forward(m, x, v_first):
     """RWKV_Tmix_x070.forward (src/model.py:163-195) with the glue fused; `m` is the module."""
     B, T, C = x.shape
-    xr, xw, xk, xv, xa, xg = mix(x, m.x_r, m.x_w, m.x_k, m.x_v, m.x_a, m.x_g)
+    train = torch.is_grad_enabled()
+    if train and GRAD_ALIAS and m.layer_id > 0:          # x_v, k2, v2 have two consumers each: aliases keep their gradients apart until the
+        xr, xw, xk, xv, xa, xg, xv_b = mix_dup3(x, m.x_r, m.x_w, m.x_k, m.x_v, m.x_a, m.x_g)      # backward kernels sum them
+    else:
+        xr, xw, xk, xv, xa, xg = mix(x, m.x_r, m.x_w, m.x_k, m.x_v, m.x_a, m.x_g)
+        xv_b = xv
     mm = lora_mm if torch.is_grad_enabled() and LORA_WGRAD else torch.matmul     # training: skinny weight-gradient kernel in the backward
     r = m.receptance(xr)
     w = decay(mm(torch.tanh(mm(xw, m.w1)), m.w2), m.w0)
@@ -409,13 +442,16 @@ def tmix_forward(m, x, v_first):
     g = mm(torch.sigmoid(mm(xg, m.g1)), m.g2)
     if m.layer_id == 0:
         v_first = v
-        k2, z, b = kva(k, None, None, None, al, m.k_k, m.k_a, m.a0, None)
-        v2 = v
+        k2, z, b, k2_b = kva(k, None, None, None, al, m.k_k, m.k_a, m.a0, None, True)
+        k2_b = k2_b if GRAD_ALIAS else k2
+        v2 = v2_b = v
     else:
-        vl = mm(mm(xv, m.v1), m.v2)
-        k2, v2, z, b = kva(k, v, v_first, vl, al, m.k_k, m.k_a, m.a0, m.v0)
+        vl = mm(mm(xv_b, m.v1), m.v2)
+        k2, v2, z, b, k2_b, v2_b = kva(k, v, v_first, vl, al, m.k_k, m.k_a, m.a0, m.v0, True)
+        if not GRAD_ALIAS:
+            k2_b, v2_b = k2, v2
     y = RUN_CUDA_RWKV7g(r, w, k2, v2, z, b)
-    y = post(y, r, k2, v2, g, m.ln_x.weight, m.ln_x.bias, m.r_k, m.ln_x.eps)
+    y = post(y, r, k2_b, v2_b, g, m.ln_x.weight, m.ln_x.bias, m.r_k, m.ln_x.eps)
     return m.output(y), v_first
 
 

@@ -39,6 +39,8 @@ PROTOTYPES = {
     "vrwkv_mix_fwd_prev_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int, _c_int] + [_c_void_p] * 5),
     "vrwkv_param_grad_ws_floats": (ctypes.c_long, [ctypes.c_long, _c_int, _c_int]),
     "vrwkv_mix_bwd_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int, _c_int] + [_c_void_p] * 7),
+    "vrwkv_mix_bwd2_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int, _c_int] + [_c_void_p] * 8),
+    "vrwkv_kva_bwd2_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int] + [_c_void_p] * 23),
     "vrwkv_decay_fwd_bf16": (_c_int, [ctypes.c_long, _c_int] + [_c_void_p] * 4),
     "vrwkv_decay_bwd_bf16": (_c_int, [ctypes.c_long, _c_int] + [_c_void_p] * 7),
     "vrwkv_kva_fwd_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int] + [_c_void_p] * 14),
