@@ -50,6 +50,18 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H,
                              void* dw, void* dq, void* dk, void* dv, void* dz, void* da,
                              void* stream);
 
+/* Sequence-parallel WKV7 backward (no counterpart in the reference): nseg workgroups per head, each
+ * walks a contiguous range of 16-token chunks of the same tensors as vrwkv_wkv7_backward_bf16.  ds_in (B,H,nseg,64,64)
+ * f32, [i][j]: dL/dS at the END of every range (NULL = zeros); ds_out, same shape: dL/dS at the START of the range.
+ * The recurrence is linear in dS -- dS_start = dS_end M^T + C with M the forward map of the range (S_end = S_start M + ..,
+ * obtained from vrwkv_wkv7_forward_state_bf16 with s0 = I, v = 0) -- so: run with ds_in = NULL to get C, scan the
+ * ranges, run again with the true ds_in for the gradients (visualrwkv_amd/wkv7.py::wkv7_backward_tparallel).
+ * 1 <= nseg <= T/16. */
+int vrwkv_wkv7_backward_segments_bf16(int B, int T, int H, int nseg, const void* w, const void* q, const void* k,
+                                      const void* v, const void* z, const void* a, const void* dy, const float* s,
+                                      const float* sa, const float* ds_in, float* ds_out,
+                                      void* dw, void* dq, void* dk, void* dv, void* dz, void* da, void* stream);
+
 /* WKV6 (BASELINE config 4): replaces cuda_forward / cuda_backward of VisualRWKV-v6/v6.0/cuda/wkv6_cuda.cu:229-242 as bound
  * by cuda/wkv6_op.cpp:8-13 (forward(B,T,C,H,r,k,v,w,u,y), backward(B,T,C,H,r,k,v,w,u,gy,gr,gk,gv,gw,gu)).
  * r,k,v,y,gy,gr,gk,gv,gw: (B,T,C) bf16; ew: (B,T,C) f32 = -exp(w_raw) as WKV_6.forward computes it (src/model.py:62);

@@ -93,3 +93,15 @@ extern "C" int emu_wgrad_skinny(long M, int Nw, int D, int S, const void* wide, 
     emu::launch(dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), [&] { lwg::reduce_kernel(part, S, Nw, D, transposed, (uint16_t*)out); });
     return 0;
 }
+
+extern "C" int emu_wkv7_backward_segments(int B, int T, int H, int nseg, const void* w, const void* q, const void* k, const void* v,
+                                          const void* z, const void* a, const void* dy, const float* s, const float* sa,
+                                          const float* ds_in, float* ds_out,
+                                          void* dw, void* dq, void* dk, void* dv, void* dz, void* da) {
+    wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
+                    (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
+                    (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
+    p.ds_in = ds_in; p.ds_out = ds_out; p.nseg = nseg;
+    emu::launch(dim3((unsigned)(B * H * nseg)), dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 2, true>(p); });
+    return 0;
+}

@@ -184,3 +184,20 @@ def test_fullsize_last_chunk_against_oracle(hip_lib, dev):
     yr, sr, sar = wkv7_c.forward(w, q, k, v, z, a)      # ~0.2 s on 8 cores
     assert rel_rms(y.float().cpu(), yr.float()) < TOL
     assert rel_rms(s.cpu()[:, :, -1], sr[:, :, -1]) < 1e-4
+
+
+@pytest.mark.parametrize("B,T,H,P", [(1, 256, 4, 4), (2, 192, 3, 2), (1, 2624, 2, 1)])
+def test_backward_tparallel_equals_sequential(B, T, H, P):
+    """Sequence-parallel backward (vrwkv_wkv7_backward_segments_bf16, two passes + scan) against the training op's
+    backward on the same inputs and checkpoints."""
+    from visualrwkv_amd import wkv7
+    w, q, k, v, z, a, dy = [t.cuda() for t in make_inputs(B, T, H, seed=T + P)]
+    y = torch.empty_like(v)
+    s = torch.empty(B, H, T // 16, 64, 64, dtype=torch.float32, device="cuda")
+    sa = torch.empty(B, T, H, 64, dtype=torch.float32, device="cuda")
+    torch.ops.wind_backstepping.forward(w, q, k, v, z, a, y, s, sa)
+    ref = [torch.empty_like(w) for _ in range(6)]
+    torch.ops.wind_backstepping.backward(w, q, k, v, z, a, dy, s, sa, *ref)
+    got = wkv7.wkv7_backward_tparallel(w, q, k, v, z, a, dy, s, sa, P)
+    for name, x, r in zip(("dw", "dq", "dk", "dv", "dz", "da"), got, ref):
+        assert rel_rms(x.float(), r.float()) < (1e-6 if P == 1 else 2e-3), name

@@ -201,7 +201,11 @@ DEVFN f32x4 mm_small2(f32x4 acc, const uint16_t (*Mh)[SS], const uint16_t (*Ml)[
 // ------------------------------------------------------------------------------------------ kernel
 // MODE bit 0: hand-off counters instead of workgroup barriers; bit 1: T doubling on the bf16 matrix core (bf16x3)
 // instead of the f32 one.  Both are kept selectable for same-process A/B timing (benchmarks/wkv7_micro.py).
-template <bool PROF, int MODE = 0>
+// TPAR: sequence-parallel launch -- blockIdx.x = (b*H + h) * nseg + seg, the workgroup walks chunks [c_lo, c_hi) of its
+// head, starting from dL/dS = ds_in[b,h,seg] and leaving dL/dS at the start of the range in ds_out (BwdArgs).  The
+// recurrence is linear in dS (dS_start = dS_end M^T + C with the forward's segment map M), so the host runs the
+// segments twice: once from zero for C, a 64x64 scan over the segments, once from the true dS_end (wkv7.py).
+template <bool PROF, int MODE = 0, bool TPAR = false>
 __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
     constexpr bool FLAGS = (MODE & 1) != 0;
     LdsB3& lds = *reinterpret_cast<LdsB3*>(dyn_lds());
@@ -211,7 +215,11 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
     const int c16 = lane & 15, g = lane >> 4;
     const int nchunk = T / L;
     const unsigned ts = (unsigned)(H * N);
-    const size_t head_base = ((size_t)(blockIdx.x / H) * T * H + (blockIdx.x % H)) * N;
+    const int nseg = TPAR ? p.nseg : 1;
+    const unsigned bh = TPAR ? blockIdx.x / (unsigned)nseg : blockIdx.x;
+    const int seg = TPAR ? (int)(blockIdx.x % (unsigned)nseg) : 0;
+    const int c_lo = TPAR ? (int)((long)nchunk * seg / nseg) : 0, c_hi = TPAR ? (int)((long)nchunk * (seg + 1) / nseg) : nchunk;
+    const size_t head_base = ((size_t)(bh / H) * T * H + (bh % H)) * N;
     WKV_STAMP_DECL
     // hand-off points: counters (FLAGS) or, at the three places marked X / Y / Z, workgroup barriers
     auto wait_c = [&](unsigned target) { if (FLAGS) lds_flag_wait(&lds.cphase, target); };
@@ -232,26 +240,26 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
             r.dy = *reinterpret_cast<const uint2*>(p.dy + o); r.sa = *reinterpret_cast<const float4*>(p.sa + o);
         };
         RawB raw;
-        fetch(raw, nchunk - 1);
+        fetch(raw, c_hi - 1);
         block_sync_lds();                                   // counters are zeroed
         // prologue ("iteration -1"): produce the last chunk completely; 3 increments per wave like every iteration
         {
             KeepB keep;
             RawB cur = raw;
-            if (nchunk > 1) fetch(raw, nchunk - 2);
-            bwd_prep_a(lds, lds.b[(nchunk - 1) & 1], cur, pw, lane, keep);
+            if (c_hi - 1 > c_lo) fetch(raw, c_hi - 2);
+            bwd_prep_a(lds, lds.b[(c_hi - 1) & 1], cur, pw, lane, keep);
             done_p();
-            bwd_prep_b(lds, lds.b[(nchunk - 1) & 1], cur, pw, lane, keep);
+            bwd_prep_b(lds, lds.b[(c_hi - 1) & 1], cur, pw, lane, keep);
             done_p();
             wait_p(8u);                                     // every producer's operand images are in LDS
             bar(); bar();                                   // X, Y
-            bwd_scores<(MODE & 2) != 0>(lds, lds.b[(nchunk - 1) & 1], pw, lane);
+            bwd_scores<(MODE & 2) != 0>(lds, lds.b[(c_hi - 1) & 1], pw, lane);
             done_p();
             bar();                                          // Z
         }
         unsigned it = 0;                                    // iteration k: consumers process chunk c, producers build c-1
-        for (int c = nchunk - 1; c >= 0; --c, ++it) {
-            const bool more = c > 0;
+        for (int c = c_hi - 1; c >= c_lo; --c, ++it) {
+            const bool more = c > c_lo;
             KeepB keep;
             RawB cur = raw;
             // P1: operand images of chunk c-1.  `opnd` is free once every producer finished the previous scores; the
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
             wait_c(12u * it);
             WKV_STAMP(0)
             if (more) {
-                if (c > 1) fetch(raw, c - 2);
+                if (c - 1 > c_lo) fetch(raw, c - 2);
                 bwd_prep_a(lds, lds.b[(c - 1) & 1], cur, pw, lane, keep);
             }
             done_p();
@@ -289,10 +297,20 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
     }
 
     // ====================================================================== consumers
-    const float* sbase = p.s + (size_t)blockIdx.x * nchunk * N * N;
+    const float* sbase = p.s + (size_t)bh * nchunk * N * N;
     f32x4 dS1[4], dS2[4], SL[4], S0n[4];
 #pragma unroll
     for (int x = 0; x < 4; ++x) { dS1[x] = zero4(); dS2[x] = zero4(); }
+    if (TPAR && p.ds_in) {       // dS1[jb][r] = dS[16w+c16][16jb+4g+r] (the S^T tiles), dS2[ib][r] = dS[16ib+4g+r][16w+c16]
+        const float* di = p.ds_in + (size_t)blockIdx.x * N * N;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const float4 t = *reinterpret_cast<const float4*>(di + (size_t)(16 * wave + c16) * N + 16 * x + 4 * g);
+            dS1[x][0] = t.x; dS1[x][1] = t.y; dS1[x][2] = t.z; dS1[x][3] = t.w;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dS2[x][r] = di[(size_t)(16 * x + 4 * g + r) * N + 16 * wave + c16];
+        }
+    }
     auto load_state = [&](f32x4* dst, int cidx) {      // s[cidx] as S[i][j] tiles: [ib][r] = S[16ib+4g+r][16w+c16]
         const float* sp = sbase + (size_t)cidx * N * N + (size_t)(16 * wave + c16) * N + 4 * g;
 #pragma unroll
@@ -301,8 +319,8 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
             dst[ib][0] = x.x; dst[ib][1] = x.y; dst[ib][2] = x.z; dst[ib][3] = x.w;
         }
     };
-    load_state(SL, nchunk - 1);
-    if (nchunk > 1) load_state(S0n, nchunk - 2);
+    load_state(SL, c_hi - 1);
+    if (c_hi > 1) load_state(S0n, c_hi - 2);
     else {
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib) S0n[ib] = zero4();
@@ -316,7 +334,7 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
     block_sync_lds();                                          // counters are zeroed
     bar(); bar(); bar();                                       // prologue X, Y, Z
     unsigned it = 0;
-    for (int c = nchunk - 1; c >= 0; --c, ++it) {
+    for (int c = c_hi - 1; c >= c_lo; --c, ++it) {
         const BufB& B = lds.b[c & 1];
         // C1 may start when buffer c&1 is complete (producers' previous iteration) and every consumer has left the
         // previous tail (its bounce strips alias dr/drT, which this segment overwrites)
@@ -494,6 +512,12 @@ __global__ __launch_bounds__(512) void bwd_kernel_v3(BwdArgs p) {
         done_c();
         bar();                                              // Z
         WKV_STAMP(4)
+    }
+    if (TPAR && p.ds_out) {
+        float* dout = p.ds_out + (size_t)blockIdx.x * N * N;
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+            *reinterpret_cast<float4*>(dout + (size_t)(16 * wave + c16) * N + 16 * x + 4 * g) = make_float4(dS1[x][0], dS1[x][1], dS1[x][2], dS1[x][3]);
     }
     WKV_STAMP_FLUSH(0, 0, 6)
 }

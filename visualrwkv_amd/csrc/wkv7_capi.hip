@@ -174,6 +174,34 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H, const void* w, const void* q, 
     return finish_launch();
 }
 
+int vrwkv_wkv7_backward_segments_bf16(int B, int T, int H, int nseg, const void* w, const void* q, const void* k, const void* v,
+                                      const void* z, const void* a, const void* dy, const float* s, const float* sa,
+                                      const float* ds_in, float* ds_out,
+                                      void* dw, void* dq, void* dk, void* dv, void* dz, void* da, void* stream) {
+    int rc = check_common(B, T, H);
+    if (rc) return rc;
+    if (!w || !q || !k || !v || !z || !a || !dy || !s || !sa || !dw || !dq || !dk || !dv || !dz || !da) return VRWKV_EINVAL;
+    if (nseg < 1 || nseg > T / VRWKV_CHUNK_LEN) return VRWKV_ESHAPE;
+    if (misaligned(w) || misaligned(q) || misaligned(k) || misaligned(v) || misaligned(z) || misaligned(a) ||
+        misaligned(dy) || misaligned(s) || misaligned(sa) || misaligned(dw) || misaligned(dq) || misaligned(dk) ||
+        misaligned(dv) || misaligned(dz) || misaligned(da) || misaligned(ds_in) || misaligned(ds_out))
+        return VRWKV_EALIGN;
+    wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
+                    (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
+                    (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
+    p.ds_in = ds_in; p.ds_out = ds_out; p.nseg = nseg;
+    auto kern = &wkv7c::bwd_kernel_v3<false, BWD_V3_DEFAULT_MODE, true>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)sizeof(wkv7c::LdsB3));
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((long)B * H * nseg)), dim3(512), sizeof(wkv7c::LdsB3), (hipStream_t)stream, p);
+    return finish_launch();
+}
+
 // Profiling builds of the chunked kernels: dbg[0..15] (device, zeroed by the caller) receives the shader-clock
 // cycles workgroup 0 spent in each phase (see WKV_STAMP in wkv7_chunked*.h).
 int vrwkv_wkv7_profile_bf16(int backward, int B, int T, int H, const void* w, const void* q, const void* k, const void* v,

@@ -183,6 +183,11 @@ struct BwdArgs {
     const float* sa;                              // f32 (B,T,H,N)
     uint16_t *dw, *dq, *dk, *dv, *dz, *da;        // bf16 (B,T,H,N)
     unsigned long long* dbg = nullptr;
+    // sequence-parallel backward (bwd_kernel_v3<.., TPAR = true>): nseg workgroups per head, each walks a contiguous range
+    // of chunks from ds_in[b,h,seg] (dL/dS at the END of its range; null = 0) and leaves dL/dS at the START in ds_out
+    const float* ds_in = nullptr;                 // f32 (B,H,nseg,N,N), [i][j]
+    float* ds_out = nullptr;
+    int nseg = 1;
 };
 
 // One workgroup (4 waves) per head; wave `wv` owns state rows [16 wv, 16 wv + 16).  The backward

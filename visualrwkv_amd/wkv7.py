@@ -241,6 +241,51 @@ def wkv7_forward_tparallel(w, q, k, v, z, a, state0=None, segments=None):
     return y.view(B, T, H, HEAD_SIZE), cur
 
 
+def wkv7_backward_tparallel(w, q, k, v, z, a, dy, s, sa, segments):
+    """Sequence-parallel backward for few heads (the training op's arguments plus a segment count).
+    dL/dS obeys dS_start = dS_end M_p^T + C_p over segment p, with M_p the forward map of the segment
+    (S_end = S_start M_p + ..).  Launches over all B*H*P (head, segment) pairs:
+      1. M_p   : forward of every segment from S = I with v = 0 (as in wkv7_forward_tparallel)
+      2. C_p   : backward of every segment from dS_end = 0 (its gradients are discarded)
+      (then P - 1 products of 64x64 matrices per head chain the segment-end dS)
+      3. grads : backward of every segment from its true dS_end.
+    ~2.5x the work of the sequential backward on P times the workgroups.  Returns (dw, dq, dk, dv, dz, da)."""
+    B, T, H = _dims(w)
+    P = int(segments)
+    if P < 1 or T % P != 0 or (T // P) % CHUNK_LEN != 0:
+        raise ValueError(f"wkv7: T = {T} cannot be cut into {P} segments of whole {CHUNK_LEN}-token chunks")
+    for n, t in zip(("w", "q", "k", "v", "z", "a", "dy"), (w, q, k, v, z, a, dy)):
+        _check_act(n, t, B, T, H)
+    _check_state(s, sa, B, T, H, w.device)
+    grads = [torch.empty_like(w) for _ in range(6)]
+    lib = hip_lib.load()
+
+    def launch(ds_in, ds_out):
+        with torch.cuda.device(w.device):
+            rc = lib.vrwkv_wkv7_backward_segments_bf16(
+                B, T, H, P, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), z.data_ptr(), a.data_ptr(), dy.data_ptr(),
+                s.data_ptr(), sa.data_ptr(), ds_in.data_ptr() if ds_in is not None else 0,
+                ds_out.data_ptr() if ds_out is not None else 0, *[g.data_ptr() for g in grads],
+                torch.cuda.current_stream(w.device).cuda_stream)
+        hip_lib.check(rc, "vrwkv_wkv7_backward_segments_bf16")
+
+    if P == 1:
+        launch(None, None)
+        return tuple(grads)
+    Ts = T // P
+    seg = [t.view(B * P, Ts, H, HEAD_SIZE) for t in (w, q, k, v, z, a)]
+    eye = torch.eye(HEAD_SIZE, dtype=torch.float32, device=w.device).expand(B * P, H, HEAD_SIZE, HEAD_SIZE).contiguous()
+    _, m_p = wkv7_forward_state(seg[0], seg[1], seg[2], torch.zeros_like(seg[3]), seg[4], seg[5], eye)
+    m_p = m_p.view(B, P, H, HEAD_SIZE, HEAD_SIZE)
+    c_p = torch.empty(B, H, P, HEAD_SIZE, HEAD_SIZE, dtype=torch.float32, device=w.device)
+    launch(None, c_p)
+    ds_end = torch.zeros_like(c_p)
+    for p in range(P - 1, 0, -1):
+        ds_end[:, :, p - 1] = torch.matmul(ds_end[:, :, p], m_p[:, p].transpose(-1, -2)) + c_p[:, :, p]
+    launch(ds_end, None)
+    return tuple(grads)
+
+
 def wkv7_step(w, q, k, v, z, a, state):
     """One token: (B,H,64) bf16 each, `state` (B,H,64,64) fp32 updated in place; returns y (B,H,64) bf16."""
     B, H, C = w.shape
