@@ -17,6 +17,8 @@ The reference's own ``src/model.py`` works unchanged on top of this module if it
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import hip_lib
@@ -34,6 +36,7 @@ _BWD_SCHEMA = ("backward(Tensor w, Tensor q, Tensor k, Tensor v, Tensor z, Tenso
 # Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).  When
 # `EVENT_LOG` is a list, every op call appends (kind, start_event, end_event, B*T*H*64).
 EVENT_LOG = None
+TPARALLEL_BWD = os.environ.get("VRWKV_TPAR_BWD", "0") == "1"     # not the default until it has been timed on the GPU
 
 
 def _timed(kind, elems, stream_dev, fn):
@@ -156,6 +159,11 @@ class WindBackstepping(torch.autograd.Function):
         assert all(i.dtype == torch.bfloat16 for i in [dy])
         assert all(i.is_contiguous() for i in [dy])
         w, q, k, v, z, b, s, sa = ctx.saved_tensors
+        if TPARALLEL_BWD and w.is_cuda:                 # opt-in (VRWKV_TPAR_BWD=1): few heads -> sequence-parallel backward
+            B, T, H, _ = w.shape
+            P = tparallel_segments(B, H, T)
+            if P > 1:
+                return wkv7_backward_tparallel(w, q, k, v, z, b, dy, s, sa, P)
         dw, dq, dk, dv, dz, db = [torch.empty_like(x) for x in [w, q, k, v, z, b]]
         torch.ops.wind_backstepping.backward(w, q, k, v, z, b, dy, s, sa, dw, dq, dk, dv, dz, db)
         return dw, dq, dk, dv, dz, db
