@@ -105,3 +105,12 @@ extern "C" int emu_wkv7_backward_segments(int B, int T, int H, int nseg, const v
     emu::launch(dim3((unsigned)(B * H * nseg)), dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 2, true>(p); });
     return 0;
 }
+
+extern "C" int emu_wkv7_forward_state_train(int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
+                                            const void* z, const void* a, void* y, const float* s0, float* s_final,
+                                            float* s_ckpt, float* sa) {
+    wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
+                    (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, s_ckpt, sa, nullptr, s0, s_final};
+    emu::launch(dim3((unsigned)(B * H)), dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1>(p); });
+    return 0;
+}

@@ -64,8 +64,8 @@ def test_host_function_on_the_emulator(emu_lib, monkeypatch):
     class Shim:
         @staticmethod
         def vrwkv_wkv7_forward_state_bf16(B, T, H, w, q, k, v, z, a, y, s0, s_fin, s_ckpt, sa, stream):
-            assert not s_ckpt and not sa
-            return emu_lib.emu_wkv7_forward_state(B, T, H, V(w), V(q), V(k), V(v), V(z), V(a), V(y), V(s0), V(s_fin))
+            return emu_lib.emu_wkv7_forward_state_train(B, T, H, V(w), V(q), V(k), V(v), V(z), V(a), V(y), V(s0), V(s_fin),
+                                                        V(s_ckpt), V(sa))
 
         @staticmethod
         def vrwkv_wkv7_backward_segments_bf16(B, T, H, P_, w, q, k, v, z, a, dy, s, sa, ds_in, ds_out, dw, dq, dk, dv, dz, da, stream):
@@ -93,3 +93,11 @@ def test_host_function_on_the_emulator(emu_lib, monkeypatch):
     one = wkv7.wkv7_backward_tparallel(w, q, k, v, z, a, dy, s, sa, 1)          # one segment = the sequential kernel
     for a_, b_ in zip(one, ref):
         assert torch.equal(a_, b_)
+
+    # the sequence-parallel forward with the training by-products (segment views + re-ordered checkpoints)
+    y_t, fin, s_t, sa_t = wkv7.wkv7_forward_tparallel(w, q, k, v, z, a, segments=nseg, train=True)
+    assert rel_rms(y_t.float(), y.float()) < 3e-3
+    assert s_t.shape == s.shape and rel_rms(s_t, s) < 1e-4 and rel_rms(sa_t, sa) < 1e-4
+    assert rel_rms(fin, s[:, :, -1].transpose(-1, -2)) < 1e-4              # checkpoints hold S^T, the state tensors S
+    y_1, _, s_1, sa_1 = wkv7.wkv7_forward_tparallel(w, q, k, v, z, a, segments=1, train=True)
+    assert torch.equal(y_1, y) and torch.equal(s_1, s) and torch.equal(sa_1, sa)

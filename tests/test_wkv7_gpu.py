@@ -201,3 +201,30 @@ def test_backward_tparallel_equals_sequential(B, T, H, P):
     got = wkv7.wkv7_backward_tparallel(w, q, k, v, z, a, dy, s, sa, P)
     for name, x, r in zip(("dw", "dq", "dk", "dv", "dz", "da"), got, ref):
         assert rel_rms(x.float(), r.float()) < 2e-3, name          # bf16 outputs; the scan re-associates the fp32 state products
+
+
+def test_tparallel_training_op_equals_default(monkeypatch):
+    """VRWKV_TPAR_BWD: WindBackstepping through the sequence-parallel forward (with checkpoints and sa) and backward
+    against the default kernels, few heads (B*H = 4)."""
+    from visualrwkv_amd import wkv7
+    B, T, H = 1, 1024, 4
+    assert wkv7.tparallel_segments(B, H, T) > 1
+    w, q, k, v, z, a, dy = [t.cuda() for t in make_inputs(B, T, H, seed=21)]
+
+    def run():
+        leaves = [t.clone().requires_grad_() for t in (w, q, k, v, z, a)]
+        y = wkv7.WindBackstepping.apply(*leaves)
+        y.backward(dy)
+        return [y.detach()] + [t.grad for t in leaves]
+
+    ref = run()
+    monkeypatch.setattr(wkv7, "TPARALLEL_BWD", True)
+    got = run()
+    for name, x, r in zip(("y", "dw", "dq", "dk", "dv", "dz", "da"), got, ref):
+        assert rel_rms(x.float(), r.float()) < 3e-3, name
+    y, fin, s, sa = wkv7.wkv7_forward_tparallel(w, q, k, v, z, a, segments=4, train=True)
+    y0 = torch.empty_like(v)
+    s0 = torch.empty(B, H, T // 16, 64, 64, dtype=torch.float32, device="cuda")
+    sa0 = torch.empty(B, T, H, 64, dtype=torch.float32, device="cuda")
+    torch.ops.wind_backstepping.forward(w, q, k, v, z, a, y0, s0, sa0)
+    assert rel_rms(s, s0) < 1e-4 and rel_rms(sa, sa0) < 1e-4 and rel_rms(y.float(), y0.float()) < 3e-3

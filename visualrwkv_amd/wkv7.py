@@ -36,7 +36,8 @@ _BWD_SCHEMA = ("backward(Tensor w, Tensor q, Tensor k, Tensor v, Tensor z, Tenso
 # Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).  When
 # `EVENT_LOG` is a list, every op call appends (kind, start_event, end_event, B*T*H*64).
 EVENT_LOG = None
-TPARALLEL_BWD = os.environ.get("VRWKV_TPAR_BWD", "0") == "1"     # not the default until it has been timed on the GPU
+TPARALLEL_BWD = os.environ.get("VRWKV_TPAR_BWD", "0") == "1"     # sequence-parallel training op for few heads; not the
+                                                                 # default until it has been timed on the GPU
 
 
 def _timed(kind, elems, stream_dev, fn):
@@ -147,10 +148,14 @@ class WindBackstepping(torch.autograd.Function):
         assert T % CHUNK_LEN == 0
         assert all(i.dtype == torch.bfloat16 for i in [w, q, k, v, z, b])
         assert all(i.is_contiguous() for i in [w, q, k, v, z, b])
-        y = torch.empty_like(v)
-        s = torch.empty(B, H, T // CHUNK_LEN, C, C, dtype=torch.float32, device=w.device)
-        sa = torch.empty(B, T, H, C, dtype=torch.float32, device=w.device)
-        torch.ops.wind_backstepping.forward(w, q, k, v, z, b, y, s, sa)
+        P = tparallel_segments(B, H, T) if TPARALLEL_BWD and w.is_cuda else 1
+        if P > 1:                                       # opt-in: few heads -> sequence-parallel forward (and backward)
+            y, _, s, sa = wkv7_forward_tparallel(w, q, k, v, z, b, segments=P, train=True)
+        else:
+            y = torch.empty_like(v)
+            s = torch.empty(B, H, T // CHUNK_LEN, C, C, dtype=torch.float32, device=w.device)
+            sa = torch.empty(B, T, H, C, dtype=torch.float32, device=w.device)
+            torch.ops.wind_backstepping.forward(w, q, k, v, z, b, y, s, sa)
         ctx.save_for_backward(w, q, k, v, z, b, s, sa)
         return y
 
@@ -180,23 +185,29 @@ def RUN_CUDA_RWKV7g(q, w, k, v, a, b):
 # Stateful generation.  Not in the reference, whose generate() re-runs the full forward for
 # every new token (src/model.py:513-529); same recurrence, state carried between calls.
 # ---------------------------------------------------------------------------------------------------------------
-def wkv7_forward_state(w, q, k, v, z, a, state0=None, want_state=True):
+def wkv7_forward_state(w, q, k, v, z, a, state0=None, want_state=True, s_ckpt=None, sa=None):
     """Forward from an explicit state, without the training by-products: (B,T,H,64) bf16 inputs, T % 16 == 0,
     state0 (B,H,64,64) fp32 in [value row][key column] order or None (= zeros).  Returns (y, final state or None).
-    The kernel neither writes the chunk checkpoints nor `sa` (22 of the training forward's 24 output bytes per element)."""
+    The kernel neither writes the chunk checkpoints nor `sa` (22 of the training forward's 24 output bytes per element)
+    unless the caller passes buffers for them (s_ckpt (B,H,T/16,64,64), sa (B,T,H,64), fp32)."""
     B, T, H = _dims(w)
     for n, t in zip("wqkvza", (w, q, k, v, z, a)):
         _check_act(n, t, B, T, H)
     if state0 is not None and (state0.dtype != torch.float32 or not state0.is_contiguous()
                                or tuple(state0.shape) != (B, H, HEAD_SIZE, HEAD_SIZE) or state0.device != w.device):
         raise ValueError(f"wkv7: state0 must be a contiguous fp32 ({B},{H},{HEAD_SIZE},{HEAD_SIZE}) tensor on {w.device}")
+    if (s_ckpt is None) != (sa is None):
+        raise ValueError("wkv7: s_ckpt and sa go together")
+    if s_ckpt is not None:
+        _check_state(s_ckpt, sa, B, T, H, w.device)
     y = torch.empty_like(v)
     s_fin = torch.empty(B, H, HEAD_SIZE, HEAD_SIZE, dtype=torch.float32, device=w.device) if want_state else None
     lib = hip_lib.load()
     with torch.cuda.device(w.device):
         rc = lib.vrwkv_wkv7_forward_state_bf16(B, T, H, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), z.data_ptr(),
                                                a.data_ptr(), y.data_ptr(), state0.data_ptr() if state0 is not None else 0,
-                                               s_fin.data_ptr() if want_state else 0, 0, 0,
+                                               s_fin.data_ptr() if want_state else 0,
+                                               s_ckpt.data_ptr() if s_ckpt is not None else 0, sa.data_ptr() if sa is not None else 0,
                                                torch.cuda.current_stream(w.device).cuda_stream)
     hip_lib.check(rc, "vrwkv_wkv7_forward_state_bf16")
     return y, s_fin
@@ -218,18 +229,23 @@ def tparallel_segments(B, H, T, n_cu=256, max_segments=16):
     return p if p >= 3 else 1                       # three passes: fewer than 3 segments cannot win
 
 
-def wkv7_forward_tparallel(w, q, k, v, z, a, state0=None, segments=None):
+def wkv7_forward_tparallel(w, q, k, v, z, a, state0=None, segments=None, train=False):
     """Sequence-parallel forward for few heads (inference prefill: B*H = 32 workgroups on 256 CUs).  The recurrence
     is linear in the state, S_end = S_start M_p + B_p per segment p, with M_p (64x64, acting on the key index) and
     B_p independent of S_start.  Three launches over all B*P*H (segment, head) pairs:
       1. B_p  : every segment from S = 0                       2. M_p : every segment from S = I with v = 0
       (then P tiny 64x64 products per head chain the segment-start states)
       3. y    : every segment from its true start state.
-    Returns (y, final state)."""
+    Returns (y, final state); with train=True also the training op's by-products: (y, final state, s, sa)."""
     B, T, H = _dims(w)
     P = segments if segments is not None else tparallel_segments(B, H, T)
     if P <= 1:
-        return wkv7_forward_state(w, q, k, v, z, a, state0)
+        if not train:
+            return wkv7_forward_state(w, q, k, v, z, a, state0)
+        s = torch.empty(B, H, T // CHUNK_LEN, HEAD_SIZE, HEAD_SIZE, dtype=torch.float32, device=w.device)
+        sa = torch.empty(B, T, H, HEAD_SIZE, dtype=torch.float32, device=w.device)
+        y, fin = wkv7_forward_state(w, q, k, v, z, a, state0, s_ckpt=s, sa=sa)
+        return y, fin, s, sa
     if T % P != 0 or (T // P) % CHUNK_LEN != 0:
         raise ValueError(f"wkv7: T = {T} cannot be cut into {P} segments of whole {CHUNK_LEN}-token chunks")
     Ts = T // P
@@ -245,8 +261,17 @@ def wkv7_forward_tparallel(w, q, k, v, z, a, state0=None, segments=None):
         starts.append(cur)
         cur = torch.matmul(cur, m_p[:, p]) + b_p[:, p]
     s0 = torch.stack(starts, dim=1).view(B * P, H, HEAD_SIZE, HEAD_SIZE).contiguous()
-    y, _ = wkv7_forward_state(*seg, s0, want_state=False)
-    return y.view(B, T, H, HEAD_SIZE), cur
+    if not train:
+        y, _ = wkv7_forward_state(*seg, s0, want_state=False)
+        return y.view(B, T, H, HEAD_SIZE), cur
+    # training by-products: `sa` is token-major, so the segment view writes it in place; the chunk checkpoints come out
+    # as (B*P, H, Ts/16, ..) and are re-ordered to the op's (B, H, T/16, ..) with one copy
+    nc = Ts // CHUNK_LEN
+    s_seg = torch.empty(B * P, H, nc, HEAD_SIZE, HEAD_SIZE, dtype=torch.float32, device=w.device)
+    sa = torch.empty(B, T, H, HEAD_SIZE, dtype=torch.float32, device=w.device)
+    y, _ = wkv7_forward_state(*seg, s0, want_state=False, s_ckpt=s_seg, sa=sa.view(B * P, Ts, H, HEAD_SIZE))
+    s = s_seg.view(B, P, H, nc, HEAD_SIZE, HEAD_SIZE).transpose(1, 2).reshape(B, H, P * nc, HEAD_SIZE, HEAD_SIZE)
+    return y.view(B, T, H, HEAD_SIZE), cur, s, sa
 
 
 def wkv7_backward_tparallel(w, q, k, v, z, a, dy, s, sa, segments):
