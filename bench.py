@@ -97,15 +97,21 @@ def cpu_baseline(n_embd, T):
     x = (torch.randn(1, T, n_embd) * 0.5).requires_grad_(True)
     vf = torch.randn(1, T, n_embd) * 0.5
     times = []
-    for it in range(2):
+    for it in range(6):                         # 1 warm-up + 5 timed runs, median
         t0 = time.perf_counter()
         y, _ = rwkv7_cpu.block(st, "b.", x, vf, 1, n_embd // 64)
         y.sum().backward()
         times.append(time.perf_counter() - t0)
-    t = min(times[1:])
-    return {"value": T / (24 * t), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"1 of 24 RWKV-7 1.5B blocks (Tmix with the C WKV7 oracle + CMix), fwd+bwd, fp32, B=1 T={T}; "
-                      f"{t:.2f} s per block, scaled x24; head/loss/ViT/optimizer not included"}
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), model)
+    except OSError:
+        pass
+    return {"value": T / (24 * t), "unit": "tokens/s", "cores": cores, "kind": "port", "cpu_model": model,
+            "sample": f"1 of 24 RWKV-7 1.5B blocks (Tmix with the C WKV7 oracle + CMix), fwd+bwd, fp32, B=1 T={T}; median of 5 "
+                      f"runs after 1 warm-up, {t:.2f} s per block, scaled x24; head/loss/ViT/optimizer not included"}
 
 
 def main():
