@@ -103,13 +103,29 @@ def cpu_baseline(n_embd, T):
         y.sum().backward()
         times.append(time.perf_counter() - t0)
     t = sorted(times[1:])[len(times[1:]) // 2]
+    # the WKV7 operator alone (the C restatement of the reference kernels, OpenMP over heads), same byte formula as the
+    # GPU roofline: tokens/s per layer and effective GB/s
+    from oracle.wkv7_oracle import make_inputs
+    H = n_embd // 64
+    ow, oq, ok_, ov, oz, oa, ody = make_inputs(1, T, H, seed=42)
+    kt = {"fwd": [], "bwd": []}
+    for it in range(4):
+        t0 = time.perf_counter()
+        _, os_, osa = wkv7_c.forward(ow, oq, ok_, ov, oz, oa)
+        t1 = time.perf_counter()
+        wkv7_c.backward(ow, oq, ok_, ov, oz, oa, ody, os_, osa)
+        kt["fwd"].append(t1 - t0); kt["bwd"].append(time.perf_counter() - t1)
+    kf, kb = sorted(kt["fwd"][1:])[1], sorted(kt["bwd"][1:])[1]
+    elems = T * H * 64
+    kernel = {"shape": [1, T, H, 64], "fwd_ms": kf * 1e3, "bwd_ms": kb * 1e3, "fwd_GBps": elems * FWD_B / kf / 1e9,
+              "bwd_GBps": elems * BWD_B / kb / 1e9, "tokens_per_s_per_layer": T / (kf + kb)}
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
             model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), model)
     except OSError:
         pass
-    return {"value": T / (24 * t), "unit": "tokens/s", "cores": cores, "kind": "port", "cpu_model": model,
+    return {"value": T / (24 * t), "unit": "tokens/s", "cores": cores, "kind": "port", "cpu_model": model, "wkv7_kernel": kernel,
             "sample": f"1 of 24 RWKV-7 1.5B blocks (Tmix with the C WKV7 oracle + CMix), fwd+bwd, fp32, B=1 T={T}; median of 5 "
                       f"runs after 1 warm-up, {t:.2f} s per block, scaled x24; head/loss/ViT/optimizer not included"}
 
