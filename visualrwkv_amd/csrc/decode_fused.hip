@@ -1,11 +1,14 @@
 // Fused per-token kernels of the decode step (stateful generation).  At T = 1 a layer of
 // RWKV_Tmix_x070 / RWKV_CMix_x070 (VisualRWKV-v7/v7.00/src/model.py:166-194,221-227,247-254) is launch-bound: the
-// captured step spends ~8 us per kernel whatever the kernel does.  Two kernels replace nine launches per layer:
+// captured step spends ~5-8 us per kernel whatever the kernel does.
 //
-//   ln_mix_prev : LayerNorm of the residual row, token shift against the carried previous row, M lerps, and the
-//                 update of the carried row (was: layer_norm, mix_fwd_prev, copy_).
 //   tmix_head   : per (b, head): second LoRA stage of w / a / g / v-gate, decay soft-clamp, k/v/a glue, the WKV7
-//                 state step, GroupNorm + bonus + gate (was: gemv, decay_fwd, kva_fwd, wkv7_step, post_fwd).
+//                 state step, GroupNorm + bonus + gate (was: gemv, decay_fwd, kva_fwd, wkv7_step, post_fwd), plus the
+//                 replacement of the carried time-mix row as a side job.
+//   ln_mix_prev : LayerNorm of the residual row, token shift against the carried previous row, M lerps, and the
+//                 update of the carried row (was: layer_norm, mix_fwd_prev, copy_).  Used for widths the LayerNorm
+//                 fold of gemv_decode.hip does not cover (C < 512 or C > 4096); otherwise that fold does this work
+//                 inside the consuming GEMV launch.
 //
 // Intermediate tensors of the unfused path are bf16; the same roundings are kept here (rb()), so the fused step
 // tracks the unfused one to reduction-order differences.
