@@ -7,6 +7,7 @@
 #include <wkv7_fwd_v3.h>
 #include <wkv7_bwd_v3.h>
 #include <wkv7_bwd_v4.h>
+#include <wkv7_bwd_v5.h>
 #include <wkv6_chunked.h>
 
 extern "C" {
@@ -60,7 +61,9 @@ int emu_wkv7_backward_chunked(int B, int T, int H, const void* w, const void* q,
     else if (mode == 1) emu::launch(grid, dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 1>(p); });
     else if (mode == 2) emu::launch(grid, dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 2>(p); });
     else if (mode == 3) emu::launch(grid, dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 3>(p); });
-    else emu::launch(grid, dim3(768), [&] { wkv7c::bwd_kernel_v4<false>(p); });
+    else if (mode == 4) emu::launch(grid, dim3(768), [&] { wkv7c::bwd_kernel_v4<false>(p); });
+    else if (mode == 5) { emu::launch(grid, dim3(512), [&] { wkv7v5::bwd_kernel_v5<false, 2>(p); }); return (int)sizeof(wkv7v5::LdsV5); }
+    else { emu::launch(grid, dim3(512), [&] { wkv7v5::bwd_kernel_v5<false, 0>(p); }); return (int)sizeof(wkv7v5::LdsV5); }
     return (int)sizeof(wkv7c::LdsB3);
 }
 
@@ -106,11 +109,33 @@ extern "C" int emu_wkv7_backward_segments(int B, int T, int H, int nseg, const v
     return 0;
 }
 
+extern "C" int emu_wkv7_backward_segments_v5(int B, int T, int H, int nseg, const void* w, const void* q, const void* k, const void* v,
+                                             const void* z, const void* a, const void* dy, const float* s, const float* sa,
+                                             const float* ds_in, float* ds_out,
+                                             void* dw, void* dq, void* dk, void* dv, void* dz, void* da) {
+    wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
+                    (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
+                    (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
+    p.ds_in = ds_in; p.ds_out = ds_out; p.nseg = nseg;
+    emu::launch(dim3((unsigned)(B * H * nseg)), dim3(512), [&] { wkv7v5::bwd_kernel_v5<false, 0, true>(p); });
+    return 0;
+}
+
 extern "C" int emu_wkv7_forward_state_train(int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
                                             const void* z, const void* a, void* y, const float* s0, float* s_final,
                                             float* s_ckpt, float* sa) {
     wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                     (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, s_ckpt, sa, nullptr, s0, s_final};
     emu::launch(dim3((unsigned)(B * H)), dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1>(p); });
+    return 0;
+}
+
+extern "C" int emu_wkv7_backward_v5_dump(int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
+                                         const void* z, const void* a, const void* dy, const float* s, const float* sa,
+                                         void* dw, void* dq, void* dk, void* dv, void* dz, void* da, void* dbg) {
+    wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
+                    (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
+                    (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da, (unsigned long long*)dbg};
+    emu::launch(dim3((unsigned)(B * H)), dim3(512), [&] { wkv7v5::bwd_kernel_v5<false, 0, false, true>(p); });
     return 0;
 }

@@ -30,6 +30,7 @@ DEVFN void split_pk(float x0, float x1, uint32_t& hi, uint32_t& lo) {
 }
 
 DEVFN float fast_exp(float x) { return expf(x); }
+DEVFN float fast_exp2(float x) { return exp2f(x); }
 DEVFN float fast_rcp(float x) { return 1.0f / x; }
 DEVFN float fast_log(float x) { return logf(x); }
 DEVFN float fast_tanh(float x) { return tanhf(x); }
@@ -59,6 +60,12 @@ template <int K> DEVFN float dpp_shl(float x) {
     int l = lane_id();
     uint32_t r = emu_wave_read(__float_as_uint(x), l + K);
     return (l & 15) + K <= 15 ? __uint_as_float(r) : 0.f;
+}
+DEVFN float dpp_row_last(float x) { return __uint_as_float(emu_wave_read(__float_as_uint(x), lane_id() | 15)); }
+DEVFN float dpp_shr1_fill(float x, float fill) {
+    int l = lane_id();
+    uint32_t r = emu_wave_read(__float_as_uint(x), l - 1);
+    return (l & 15) >= 1 ? __uint_as_float(r) : fill;
 }
 DEVFN float lane_xor1(float x) { return lane_xor(x, 1); }
 DEVFN float lane_xor2(float x) { return lane_xor(x, 2); }
@@ -216,6 +223,8 @@ DEVFN uint2 lds_read_tr16(const uint16_t* p) {
     r.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
     return r;
 }
+DEVFN void lds_dma16(const void* gsrc, void* lds_wave_base) { memcpy((char*)lds_wave_base + 16 * (emu::flat_tid() & 63), gsrc, 16); }
+DEVFN void vmem_drain() {}
 DEVFN void lds_flag_add(unsigned* cnt) {
     emu::wave_barrier();
     if ((emu::flat_tid() & 63) == 0) *(volatile unsigned*)cnt += 1;

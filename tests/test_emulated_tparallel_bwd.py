@@ -12,9 +12,12 @@ def P(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+@pytest.mark.parametrize("gen", ["v3", "v5"])
 @pytest.mark.parametrize("T,H,nseg", [(96, 2, 3), (64, 1, 4), (80, 1, 2)])
-def test_two_pass_segments_equal_sequential_backward(emu_lib, T, H, nseg):
+def test_two_pass_segments_equal_sequential_backward(emu_lib, T, H, nseg, gen):
     B = 1
+    segments = emu_lib.emu_wkv7_backward_segments if gen == "v3" else emu_lib.emu_wkv7_backward_segments_v5
+    seq_mode = 2 if gen == "v3" else 6
     w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=T + nseg)
     y = torch.zeros_like(v)
     nch = T // 16
@@ -22,7 +25,7 @@ def test_two_pass_segments_equal_sequential_backward(emu_lib, T, H, nseg):
     sa = torch.zeros(B, T, H, 64)
     emu_lib.emu_wkv7_forward(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(y), P(s), P(sa), 5)
     ref = [torch.zeros_like(w) for _ in range(6)]
-    emu_lib.emu_wkv7_backward_chunked(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(dy), P(s), P(sa), *[P(t) for t in ref], 2)
+    emu_lib.emu_wkv7_backward_chunked(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(dy), P(s), P(sa), *[P(t) for t in ref], seq_mode)
 
     # forward maps of the segments: S_end = S_start M + ..  (forward from S = I with v = 0)
     bounds = [nch * p // nseg * 16 for p in range(nseg + 1)]
@@ -38,8 +41,7 @@ def test_two_pass_segments_equal_sequential_backward(emu_lib, T, H, nseg):
     def run(ds_in):
         ds_out = torch.zeros(B, H, nseg, 64, 64)
         g = [torch.zeros_like(w) for _ in range(6)]
-        emu_lib.emu_wkv7_backward_segments(B, T, H, nseg, P(w), P(q), P(k), P(v), P(z), P(a), P(dy), P(s), P(sa), P(ds_in), P(ds_out),
-                                           *[P(t) for t in g])
+        segments(B, T, H, nseg, P(w), P(q), P(k), P(v), P(z), P(a), P(dy), P(s), P(sa), P(ds_in), P(ds_out), *[P(t) for t in g])
         return ds_out, g
 
     C, _ = run(None)                                             # pass 1: dS at the segment starts from dS_end = 0
@@ -51,7 +53,8 @@ def test_two_pass_segments_equal_sequential_backward(emu_lib, T, H, nseg):
         assert rel_rms(a_.float(), b_.float()) < 2e-3, name      # bf16 outputs; state products in bf16x3
 
 
-def test_host_function_on_the_emulator(emu_lib, monkeypatch):
+@pytest.mark.parametrize("gen", ["v3", "v5"])
+def test_host_function_on_the_emulator(emu_lib, monkeypatch, gen):
     """visualrwkv_amd.wkv7.wkv7_backward_tparallel itself (segment views, M_p, scan, two launches), with the two C-ABI
     entries it calls redirected to the emulated kernels -- the host logic cannot run on a GPU in this suite."""
     import contextlib
@@ -69,8 +72,9 @@ def test_host_function_on_the_emulator(emu_lib, monkeypatch):
 
         @staticmethod
         def vrwkv_wkv7_backward_segments_bf16(B, T, H, P_, w, q, k, v, z, a, dy, s, sa, ds_in, ds_out, dw, dq, dk, dv, dz, da, stream):
-            return emu_lib.emu_wkv7_backward_segments(B, T, H, P_, V(w), V(q), V(k), V(v), V(z), V(a), V(dy), V(s), V(sa), V(ds_in),
-                                                      V(ds_out), V(dw), V(dq), V(dk), V(dv), V(dz), V(da))
+            fn = emu_lib.emu_wkv7_backward_segments if gen == "v3" else emu_lib.emu_wkv7_backward_segments_v5
+            return fn(B, T, H, P_, V(w), V(q), V(k), V(v), V(z), V(a), V(dy), V(s), V(sa), V(ds_in), V(ds_out), V(dw), V(dq), V(dk), V(dv),
+                      V(dz), V(da))
 
         @staticmethod
         def vrwkv_strerror(code):
@@ -86,7 +90,7 @@ def test_host_function_on_the_emulator(emu_lib, monkeypatch):
     sa = torch.zeros(B, T, H, 64)
     emu_lib.emu_wkv7_forward(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(y), P(s), P(sa), 5)
     ref = [torch.zeros_like(w) for _ in range(6)]
-    emu_lib.emu_wkv7_backward_chunked(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(dy), P(s), P(sa), *[P(t) for t in ref], 2)
+    emu_lib.emu_wkv7_backward_chunked(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(dy), P(s), P(sa), *[P(t) for t in ref], 2 if gen == "v3" else 6)
     got = wkv7.wkv7_backward_tparallel(w, q, k, v, z, a, dy, s, sa, nseg)
     for name, a_, b_ in zip(("dw", "dq", "dk", "dv", "dz", "da"), got, ref):
         assert rel_rms(a_.float(), b_.float()) < 2e-3, name

@@ -55,10 +55,11 @@ def test_backward(emu_lib):
         assert rel_rms(o.float(), r.float()) < 1e-3, name
 
 
-@pytest.mark.parametrize("mode", [-1, 0, 1, 2, 3, 4])
+@pytest.mark.parametrize("mode", [-1, 0, 1, 2, 3, 4, 5, 6])
 def test_backward_chunked(emu_lib, mode):
     """Chunked MFMA backward kernels run lane-exactly on the host: the 4-wave kernel (-1) and the 8-wave
-    producer/consumer kernel with workgroup barriers or LDS hand-off counters (bit 0) and f32 / bf16x3 doubling (bit 1)."""
+    producer/consumer kernel with workgroup barriers or LDS hand-off counters (bit 0) and f32 / bf16x3 doubling (bit 1);
+    5 / 6: second-generation schedule (wkv7_bwd_v5.h) with bf16x3 / f32 doubling."""
     B, T, H = 1, 48, 2
     w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=7 + mode)
     _, s, sa = wkv7_c.forward(w, q, k, v, z, a)

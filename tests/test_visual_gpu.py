@@ -1,0 +1,65 @@
+"""Image side of the hot path on the GPU (bf16) against the fixtures recorded from the reference's own
+src/model.py / src/sam.py (tests/golden/make_golden_model.py): projector (model.py:328-338), adaptive pooling
+(:442-447), masked scatter (:485-493, bit-exact indexing), SAM ViT encoder incl. window / global attention with the
+decomposed relative-position bias (src/sam.py:172-181,289-305,392-426)."""
+import os
+from types import SimpleNamespace
+
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle.wkv7_oracle import rel_rms
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "model_ref.pt")
+TOL = 1e-2          # bf16 pipeline against an fp32 fixture
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return torch.load(GOLD)
+
+
+def test_projector_gpu(gold):
+    from visualrwkv_amd.visual import MLPWithContextGating
+    p = MLPWithContextGating(48, 128)
+    p.load_state_dict(gold["proj"]["state"])
+    p = p.cuda().bfloat16()
+    with torch.no_grad():
+        y = p(gold["proj"]["x"].cuda().bfloat16())
+    assert rel_rms(y.float().cpu(), gold["proj"]["y"]) < TOL
+
+
+def test_adaptive_pooling_and_scatter_gpu(gold):
+    from visualrwkv_amd.visual import VisualRWKV
+    g = gold["pool"]
+    holder = SimpleNamespace(pool=nn.AdaptiveAvgPool2d(g["out_side"]), args=SimpleNamespace(fused=True))
+    y = VisualRWKV.adaptive_pooling(holder, g["x"].cuda().bfloat16())
+    assert rel_rms(y.float().cpu(), g["y"]) < 5e-3
+    s = gold["scatter"]
+    emb = nn.Embedding(65536, 8)
+    with torch.no_grad():
+        emb.weight.copy_(torch.randn(65536, 8, generator=torch.Generator().manual_seed(s["emb_seed"])))
+    emb = emb.cuda()
+    holder = SimpleNamespace(rwkv=SimpleNamespace(emb=emb), encode_images=lambda images: s["img_feats"].cuda(),
+                             args=SimpleNamespace(check_image_tokens=True, fused=True))
+    with torch.no_grad():
+        y, _ = VisualRWKV.preparing_embedding(holder, {"input_ids": s["ids"].cuda(), "labels": s["ids"].cuda(), "images": {}})
+    assert torch.equal(y.cpu(), s["y"])          # indexing is bit-exact
+
+
+def test_sam_encoder_gpu(gold):
+    """Scaled SAM configuration of the fixture (128^2 input, window 3, one global block) through the product path."""
+    from visualrwkv_amd.vit import SamImageEncoder
+    g = gold["sam"]
+    m = SamImageEncoder(img_size=128, patch=16, dim=64, depth=3, heads=2, out_chans=16, window=3, global_attn_indexes=(2,))
+    m.load_state_dict(g["state"], strict=True)
+    m = m.cuda().bfloat16()
+    with torch.no_grad():
+        h = m.patch_embed(g["x"].cuda().bfloat16()) + m.pos_embed
+        for blk in m.blocks:
+            h = blk(h)
+        neck = m.neck(h.permute(0, 3, 1, 2))
+    assert rel_rms(h.float().cpu(), g["tokens"]) < 2 * TOL
+    assert rel_rms(neck.float().cpu(), g["neck"]) < 3 * TOL

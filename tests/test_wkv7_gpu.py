@@ -60,7 +60,7 @@ def test_forward_parity(hip_lib, dev, B, T, H, variant):
     assert rel_rms(sa.cpu(), sar) < 2e-5
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, -1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, -1])
 @pytest.mark.parametrize("B,T,H", [(1, 16, 1), (2, 64, 3), (1, 384, 12), (3, 208, 5)])
 def test_backward_parity(hip_lib, dev, B, T, H, variant):
     w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=B * 77 + T + H)
@@ -184,6 +184,45 @@ def test_fullsize_last_chunk_against_oracle(hip_lib, dev):
     yr, sr, sar = wkv7_c.forward(w, q, k, v, z, a)      # ~0.2 s on 8 cores
     assert rel_rms(y.float().cpu(), yr.float()) < TOL
     assert rel_rms(s.cpu()[:, :, -1], sr[:, :, -1]) < 1e-4
+
+
+def test_cfg3_fullsize_backward_against_oracle(hip_lib, dev):
+    """BASELINE config 3 shape (1.5B: H=32, T=576+2048=2624), B=1: forward outputs and all six gradients of the
+    full-size launch against the C oracle (wkv7_cuda.cu:54-130 restated), not only through properties."""
+    B, T, H = 1, 2624, 32
+    w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=33)
+    yr, sr, sar = wkv7_c.forward(w, q, k, v, z, a)
+    ref = wkv7_c.backward(w, q, k, v, z, a, dy, sr, sar)
+    d = [x.to(dev) for x in (w, q, k, v, z, a, dy)]
+    y, s, sa = _capi_forward(hip_lib, *d[:6])
+    outs = _capi_backward(hip_lib, *d, s, sa)
+    torch.cuda.synchronize()
+    assert rel_rms(y.float().cpu(), yr.float()) < TOL
+    assert rel_rms(s.cpu(), sr) < 2e-5 and rel_rms(sa.cpu(), sar) < 2e-5
+    for n, o, r in zip(NAMES, outs, ref):
+        assert rel_rms(o.float().cpu(), r.float()) < TOL, n
+
+
+@pytest.mark.parametrize("tpar", [False, True])
+def test_cfg5_shape_fwd_bwd_parity(hip_lib, dev, monkeypatch, tpar):
+    """BASELINE config 5 shape (1.5B UHD: H=32, T=2304+4096=6400), B=1, through the autograd surface against the C
+    oracle: the default kernels and the sequence-parallel training op (128 heads... here 32 workgroups for 256 CUs)."""
+    from visualrwkv_amd import wkv7
+    B, T, H = 1, 6400, 32
+    w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=55)
+    yr, sr, sar = wkv7_c.forward(w, q, k, v, z, a)
+    ref = wkv7_c.backward(w, q, k, v, z, a, dy, sr, sar)
+    monkeypatch.setattr(wkv7, "TPARALLEL_BWD", tpar)
+    if tpar:
+        assert wkv7.tparallel_segments(B, H, T) > 1
+    leaves = [x.to(dev).requires_grad_(True) for x in (w, q, k, v, z, a)]
+    y = wkv7.WindBackstepping.apply(*leaves)
+    y.backward(dy.to(dev))
+    torch.cuda.synchronize()
+    tol = 4e-3 if tpar else TOL      # the segment scan re-associates fp32 state products: isolated 1-ulp bf16 flips
+    assert rel_rms(y.detach().float().cpu(), yr.float()) < tol
+    for n, l, r in zip(NAMES, leaves, ref):
+        assert rel_rms(l.grad.float().cpu(), r.float()) < tol, n
 
 
 @pytest.mark.parametrize("B,T,H,P", [(1, 256, 4, 4), (2, 192, 3, 2), (1, 2624, 2, 1)])

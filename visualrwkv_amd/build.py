@@ -73,7 +73,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             tmp = f"{LIB_PATH}.tmp{os.getpid()}"
             cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
                    "-I", CSRC, "-I", os.path.join(REPO_DIR, "include"),
-                   "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form", *_sources(), "-o", tmp]
+                   "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form", *os.environ.get("VRWKV_EXTRA_HIPCC_FLAGS", "").split(), *_sources(), "-o", tmp]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True)

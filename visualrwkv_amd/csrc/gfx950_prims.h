@@ -44,6 +44,7 @@ DEVFN void split_pk(float x0, float x1, uint32_t& hi, uint32_t& lo) {
 
 // ---------------------------------------------------------------- math
 DEVFN float fast_exp(float x) { return __expf(x); }          // v_exp_f32 path
+DEVFN float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // bare v_exp_f32 (no range handling: |x| small here)
 DEVFN float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 DEVFN float fast_log(float x) { return __logf(x); }
 DEVFN float fast_tanh(float x) { return tanhf(x); }
@@ -56,12 +57,19 @@ template <int CTRL> DEVFN float dpp_mov(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
 }
 // row_shr:K inside each 16-lane row; lanes whose source falls outside the row read 0
+// (bound_ctrl: out-of-row sources read 0 without a separate zero-initialised destination register)
 template <int K> DEVFN float dpp_shr(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x110 + K, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x110 + K, 0xf, 0xf, true));
 }
 // row_shl:K (lane t reads lane t+K of its 16-lane row; 0 beyond the row end)
 template <int K> DEVFN float dpp_shl(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x100 + K, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x100 + K, 0xf, 0xf, true));
+}
+// lane 15 of every 16-lane row broadcast to the whole row (row_newbcast:15, gfx90a+): one VALU op instead of ds_bpermute
+DEVFN float dpp_row_last(float x) { return dpp_mov<0x15F>(x); }
+// row_shr:1 with `fill` for the first lane of every row
+DEVFN float dpp_shr1_fill(float x, float fill) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x111, 0xf, 0xf, false));
 }
 DEVFN float lane_xor1(float x) { return dpp_mov<0xB1>(x); }        // quad_perm [1,0,3,2]
 DEVFN float lane_xor2(float x) { return dpp_mov<0x4E>(x); }        // quad_perm [2,3,0,1]
@@ -163,6 +171,22 @@ DEVFN uint2 lds_read_tr16(const uint16_t* p) {
     const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(uintptr_t)(uint32_t)(uintptr_t)p);   // low 32 bits of a generic LDS pointer = LDS offset
     return __builtin_bit_cast(uint2, v);
 }
+
+// ---------------------------------------------------------------- LDS-DMA (global -> LDS without passing through VGPRs)
+// global_load_lds_dwordx4: every lane supplies its own 16-byte global source; the destination is wave-uniform:
+// lane l lands at lds_base + 16 l.  Completion is counted by vmcnt of the issuing wave; readers in other waves need
+// that wave's s_waitcnt vmcnt followed by a workgroup barrier (vmem_drain() + block_sync_lds()).
+// Issued as inline asm on purpose: hipcc cannot tell which LDS bytes a DMA it knows about will write (all LDS here is one
+// dynamic array), so it puts s_waitcnt vmcnt(0) in front of every later LDS access of the wave -- which also drains the
+// wave's register prefetch loads (measured: +2k cycles per chunk in the WKV7 backward's producers).  The asm form is
+// invisible to its counters; the kernel waits for it explicitly.  M0 carries the LDS address (saved and restored).
+DEVFN void lds_dma16(const void* gsrc, void* lds_wave_base) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+DEVFN void vmem_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---------------------------------------------------------------- sync
 DEVFN void block_sync() { __syncthreads(); }

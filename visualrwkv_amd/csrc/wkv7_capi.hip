@@ -9,6 +9,7 @@
 #include <wkv7_fwd_v3.h>
 #include <wkv7_bwd_v3.h>
 #include <wkv7_bwd_v4.h>
+#include <wkv7_bwd_v5.h>
 
 namespace {
 
@@ -52,7 +53,7 @@ int vrwkv_wkv7_set_forward_variant(int variant) {
 }
 
 int vrwkv_wkv7_set_backward_variant(int variant) {
-    if (variant > 6) return VRWKV_EINVAL;
+    if (variant > 10) return VRWKV_EINVAL;
     g_bwd_variant = variant;
     return VRWKV_OK;
 }
@@ -133,42 +134,42 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H, const void* w, const void* q, 
                     (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)((long)B * H));
-    if (g_bwd_variant == 0) {
+    if (g_bwd_variant < 0 || (g_bwd_variant >= 7 && g_bwd_variant <= 10)) {      // default: second-generation schedule (wkv7_bwd_v5.h); 8: T doubling on the bf16 matrix core
+        auto launch5 = [&](auto kern) -> int {
+            // the > 64 KB LDS opt-in is per device: set it on every launch (cheap) instead of caching a per-process flag
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)sizeof(wkv7v5::LdsV5));
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(kern, grid, dim3(512), sizeof(wkv7v5::LdsV5), st, p);
+            return 0;
+        };
+        const int e = g_bwd_variant == 8 ? launch5(&wkv7v5::bwd_kernel_v5<false, 2>) : launch5(&wkv7v5::bwd_kernel_v5<false, 0>);
+        if (e) return e;
+    } else if (g_bwd_variant == 0) {
         hipLaunchKernelGGL((wkv7::bwd_kernel<8>), grid, dim3(256), 0, st, p);
-    } else if (g_bwd_variant < 0 || (g_bwd_variant >= 2 && g_bwd_variant <= 5)) {
+    } else if (g_bwd_variant >= 2 && g_bwd_variant <= 5) {
         // 2: barriers + f32 doubling, 3: hand-off counters, 4: barriers + bf16x3 doubling, 5: both
-        const int mode = g_bwd_variant < 0 ? BWD_V3_DEFAULT_MODE : g_bwd_variant - 2;
-        auto launch = [&](auto kern, bool& attr) -> int {
-            if (!attr) {        // > 64 KB of LDS needs the opt-in once per process
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   (int)sizeof(wkv7c::LdsB3));
-                if (e != hipSuccess) return (int)e;
-                attr = true;
-            }
+        const int mode = g_bwd_variant - 2;
+        auto launch = [&](auto kern) -> int {
+            // > 64 KB of LDS needs the opt-in per device: set on every launch (cheap), no per-process flag
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)sizeof(wkv7c::LdsB3));
+            if (e != hipSuccess) return (int)e;
             hipLaunchKernelGGL(kern, grid, dim3(512), sizeof(wkv7c::LdsB3), st, p);
             return 0;
         };
-        static bool at0 = false, at1 = false, at2 = false, at3 = false;
-        int e = mode == 0 ? launch(&wkv7c::bwd_kernel_v3<false, 0>, at0) : mode == 1 ? launch(&wkv7c::bwd_kernel_v3<false, 1>, at1)
-              : mode == 2 ? launch(&wkv7c::bwd_kernel_v3<false, 2>, at2) : launch(&wkv7c::bwd_kernel_v3<false, 3>, at3);
+        int e = mode == 0 ? launch(&wkv7c::bwd_kernel_v3<false, 0>) : mode == 1 ? launch(&wkv7c::bwd_kernel_v3<false, 1>)
+              : mode == 2 ? launch(&wkv7c::bwd_kernel_v3<false, 2>) : launch(&wkv7c::bwd_kernel_v3<false, 3>);
         if (e) return e;
     } else if (g_bwd_variant == 6) {      // 12 waves: I / J consumer roles + producers (wkv7_bwd_v4.h)
-        static bool attr4_set = false;
-        if (!attr4_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::bwd_kernel_v4<false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsB3));
-            if (e != hipSuccess) return (int)e;
-            attr4_set = true;
-        }
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::bwd_kernel_v4<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsB3));
+        if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(wkv7c::bwd_kernel_v4<false>, grid, dim3(768), sizeof(wkv7c::LdsB3), st, p);
     } else {
-        static bool attr_set = false;     // > 64 KB of LDS needs the opt-in once per process
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::bwd_kernel_t<false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsB));
-            if (e != hipSuccess) return (int)e;
-            attr_set = true;
-        }
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::bwd_kernel_t<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsB));
+        if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(wkv7c::bwd_kernel_t<false>, grid, dim3(256), sizeof(wkv7c::LdsB), st, p);
     }
     return finish_launch();
@@ -190,15 +191,20 @@ int vrwkv_wkv7_backward_segments_bf16(int B, int T, int H, int nseg, const void*
                     (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
                     (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
     p.ds_in = ds_in; p.ds_out = ds_out; p.nseg = nseg;
-    auto kern = &wkv7c::bwd_kernel_v3<false, BWD_V3_DEFAULT_MODE, true>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    const dim3 grid((unsigned)((long)B * H * nseg));
+    if (g_bwd_variant < 0 || g_bwd_variant == 7 || g_bwd_variant == 8) {
+        auto kern = &wkv7v5::bwd_kernel_v5<false, 0, true>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)sizeof(wkv7c::LdsB3));
+                                           (int)sizeof(wkv7v5::LdsV5));
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        hipLaunchKernelGGL(kern, grid, dim3(512), sizeof(wkv7v5::LdsV5), (hipStream_t)stream, p);
+        return finish_launch();
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((long)B * H * nseg)), dim3(512), sizeof(wkv7c::LdsB3), (hipStream_t)stream, p);
+    auto kern = &wkv7c::bwd_kernel_v3<false, BWD_V3_DEFAULT_MODE, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sizeof(wkv7c::LdsB3));
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, grid, dim3(512), sizeof(wkv7c::LdsB3), (hipStream_t)stream, p);
     return finish_launch();
 }
 
@@ -228,7 +234,17 @@ int vrwkv_wkv7_profile_bf16(int backward, int B, int T, int H, const void* w, co
         wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                         (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
                         (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da, dbg};
-        if (g_bwd_variant == 1) {
+        if (g_bwd_variant == 10) {      // register dump of workgroup 0 (debugging aid): dbg = float[2][24][256][4]
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7v5::bwd_kernel_v5<false, 0, false, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7v5::LdsV5));
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL((wkv7v5::bwd_kernel_v5<false, 0, false, true>), grid, dim3(512), sizeof(wkv7v5::LdsV5), st, p);
+        } else if (g_bwd_variant < 0 || g_bwd_variant == 7 || g_bwd_variant == 8) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7v5::bwd_kernel_v5<true, 0>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7v5::LdsV5));
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL((wkv7v5::bwd_kernel_v5<true, 0>), grid, dim3(512), sizeof(wkv7v5::LdsV5), st, p);
+        } else if (g_bwd_variant == 1) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::bwd_kernel_t<true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsB));
             if (e != hipSuccess) return (int)e;
