@@ -10,9 +10,10 @@ FWD = ["c_top", "c_main1", "c_waitA", "c_store_y_sa", "c_supdate_store_s", "c_wa
 BWD5 = ["c_top", "c_isplit", "c_waitX", "c_jsplit", "c_waitY", "c_seg3_tail", "c_waitZ", "-", "p_top", "p_prepA", "p_waitX", "p_prepB", "p_dM", "p_waitY", "p_scores", "p_waitZ"]
 BWD = ["c_isplit", "c_waitX", "c_jsplit", "c_waitY", "c_tail_waitZ", "c_start", "-", "-", "p_start", "p_prepA_waitX", "p_prepB", "p_flagwait", "p_dM_waitY", "p_scores_waitZ"]
 
-def run(B=8, T=2624, H=32, bwd_variant=-1):
+def run(B=8, T=2624, H=32, bwd_variant=-1, fwd_variant=-1):
     lib = hip_lib.load()
     lib.vrwkv_wkv7_set_backward_variant(bwd_variant)
+    lib.vrwkv_wkv7_set_forward_variant(fwd_variant)
     dev = "cuda:0"
     w, q, k, v, z, a, dy = synth_inputs(B, T, H, dev)
     y = torch.empty_like(v); s = torch.empty(B, H, T // 16, 64, 64, device=dev); sa = torch.empty(B, T, H, 64, device=dev)
@@ -34,4 +35,5 @@ def run(B=8, T=2624, H=32, bwd_variant=-1):
 if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     bv = int(sys.argv[2]) if len(sys.argv) > 2 else -1
-    print(json.dumps(run(B=B, bwd_variant=bv)))
+    fv = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+    print(json.dumps(run(B=B, bwd_variant=bv, fwd_variant=fv)))

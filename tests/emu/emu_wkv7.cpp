@@ -8,6 +8,7 @@
 #include <wkv7_bwd_v3.h>
 #include <wkv7_bwd_v4.h>
 #include <wkv7_bwd_v5.h>
+#include <wkv7_fwd_v5.h>
 #include <wkv6_chunked.h>
 
 extern "C" {
@@ -23,6 +24,8 @@ int emu_wkv7_forward(int B, int T, int H, const void* w, const void* q, const vo
     else if (variant == 3) emu::launch(grid, dim3(256), [&] { wkv7c::fwd_kernel_t<false>(p); });
     else if (variant == 4) emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false>(p); });                       // wide stores
     else if (variant == 5) emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1>(p); });             // narrow stores
+    else if (variant == 12) emu::launch(grid, dim3(512), [&] { wkv7v5::fwd_kernel_v5<false, 0>(p); });                  // second-generation schedule
+    else if (variant == 13) emu::launch(grid, dim3(512), [&] { wkv7v5::fwd_kernel_v5<false, 2>(p); });
     else if (variant == 10) emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1, 2, true>(p); });  // + prefetch 2, DPP suffix
     else emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1, 1, false, true>(p); });              // transpose reads
     return 0;
@@ -137,5 +140,13 @@ extern "C" int emu_wkv7_backward_v5_dump(int B, int T, int H, const void* w, con
                     (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
                     (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da, (unsigned long long*)dbg};
     emu::launch(dim3((unsigned)(B * H)), dim3(512), [&] { wkv7v5::bwd_kernel_v5<false, 0, false, true>(p); });
+    return 0;
+}
+
+extern "C" int emu_wkv7_forward_state_v5(int B, int T, int H, const void* w, const void* q, const void* k, const void* v, const void* z,
+                                         const void* a, void* y, const float* s0, float* s_final, float* s_ckpt, float* sa) {
+    wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
+                    (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, s_ckpt, sa, nullptr, s0, s_final};
+    emu::launch(dim3((unsigned)(B * H)), dim3(512), [&] { wkv7v5::fwd_kernel_v5<false, 0>(p); });
     return 0;
 }

@@ -14,7 +14,7 @@ def P(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 10, 11])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 10, 11, 12, 13])
 def test_forward_variants(emu_lib, variant):
     B, T, H, N = 2, 32, 2, 64
     w, q, k, v, z, a, _ = make_inputs(B, T, H, seed=variant)

@@ -44,7 +44,7 @@ def _capi_backward(lib, w, q, k, v, z, a, dy, s, sa):
     return outs
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 8, 9, 10, 11, -1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13, -1])
 @pytest.mark.parametrize("B,T,H", [(1, 16, 1), (2, 64, 3), (1, 384, 12), (3, 208, 5)])
 def test_forward_parity(hip_lib, dev, B, T, H, variant):
     w, q, k, v, z, a, _ = make_inputs(B, T, H, seed=B * 1000 + T + H)
@@ -244,8 +244,8 @@ def test_backward_tparallel_equals_sequential(B, T, H, P):
 
 
 def test_tparallel_training_op_equals_default(monkeypatch):
-    """VRWKV_TPAR_BWD: WindBackstepping through the sequence-parallel forward (with checkpoints and sa) and backward
-    against the default kernels, few heads (B*H = 4)."""
+    """WindBackstepping through the sequence-parallel forward (with checkpoints and sa) and backward against the
+    sequential kernels, few heads (B*H = 4)."""
     from visualrwkv_amd import wkv7
     B, T, H = 1, 1024, 4
     assert wkv7.tparallel_segments(B, H, T) > 1
@@ -257,8 +257,10 @@ def test_tparallel_training_op_equals_default(monkeypatch):
         y.backward(dy)
         return [y.detach()] + [t.grad for t in leaves]
 
+    monkeypatch.setattr(wkv7, "TPARALLEL_BWD", False)
     ref = run()
     monkeypatch.setattr(wkv7, "TPARALLEL_BWD", True)
+    monkeypatch.setattr(wkv7, "_TPAR_ENV", "1")          # also the forward, which the measured default only cuts for T >= 4096
     got = run()
     for name, x, r in zip(("y", "dw", "dq", "dk", "dv", "dz", "da"), got, ref):
         assert rel_rms(x.float(), r.float()) < 4e-3, name

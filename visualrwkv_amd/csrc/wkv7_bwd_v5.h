@@ -301,6 +301,8 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
     if (wave >= 4) {
         // ================================================================== producers (one chunk ahead; loads only)
         const int pw = wave - 4;
+        // static priority for the producers (the younger half of the workgroup loses VALU arbitration otherwise): -7 % kernel time
+        if (MODE & 8) wave_priority<3>(); else if (MODE & 4) wave_priority<2>(); else wave_priority<1>();
         const LaneAddr la = lane_addr(c16, g, pw);
         const unsigned lane_off = (unsigned)c16 * ts + 16u * pw + 4u * g;
         auto fetch = [&](RawB& r, int c) {

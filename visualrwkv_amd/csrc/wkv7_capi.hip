@@ -10,6 +10,7 @@
 #include <wkv7_bwd_v3.h>
 #include <wkv7_bwd_v4.h>
 #include <wkv7_bwd_v5.h>
+#include <wkv7_fwd_v5.h>
 
 namespace {
 
@@ -47,13 +48,13 @@ const char* vrwkv_strerror(int code) {
 }
 
 int vrwkv_wkv7_set_forward_variant(int variant) {
-    if (variant > 11) return VRWKV_EINVAL;
+    if (variant > 13) return VRWKV_EINVAL;
     g_fwd_variant = variant;
     return VRWKV_OK;
 }
 
 int vrwkv_wkv7_set_backward_variant(int variant) {
-    if (variant > 10) return VRWKV_EINVAL;
+    if (variant > 12) return VRWKV_EINVAL;
     g_bwd_variant = variant;
     return VRWKV_OK;
 }
@@ -73,7 +74,17 @@ int vrwkv_wkv7_forward_bf16(int B, int T, int H, const void* w, const void* q, c
     int variant = g_fwd_variant;
     if (variant < 0) variant = 5;                                           // chunked MFMA, producer/consumer waves
     const dim3 grid((unsigned)heads);
-    if (variant == 0) hipLaunchKernelGGL((wkv7::fwd_kernel<16, 8>), grid, dim3(64), 0, st, p);
+    if (variant == 12 || variant == 13) {           // second-generation schedule (wkv7_fwd_v5.h); 13: T chain on the bf16 matrix core
+        auto launch5 = [&](auto kern) -> int {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)sizeof(wkv7v5::LdsF5));
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(kern, grid, dim3(512), sizeof(wkv7v5::LdsF5), st, p);
+            return 0;
+        };
+        const int e = variant == 12 ? launch5(&wkv7v5::fwd_kernel_v5<false, 0>) : launch5(&wkv7v5::fwd_kernel_v5<false, 2>);
+        if (e) return e;
+    } else if (variant == 0) hipLaunchKernelGGL((wkv7::fwd_kernel<16, 8>), grid, dim3(64), 0, st, p);
     else if (variant == 1) hipLaunchKernelGGL((wkv7::fwd_kernel<8, 16>), grid, dim3(128), 0, st, p);
     else if (variant == 2) hipLaunchKernelGGL((wkv7::fwd_kernel<4, 16>), grid, dim3(256), 0, st, p);
     else if (variant == 3) hipLaunchKernelGGL(wkv7c::fwd_kernel_t<false>, grid, dim3(256), 0, st, p);
@@ -134,7 +145,7 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H, const void* w, const void* q, 
                     (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)((long)B * H));
-    if (g_bwd_variant < 0 || (g_bwd_variant >= 7 && g_bwd_variant <= 10)) {      // default: second-generation schedule (wkv7_bwd_v5.h); 8: T doubling on the bf16 matrix core
+    if (g_bwd_variant < 0 || (g_bwd_variant >= 7 && g_bwd_variant <= 12)) {      // default: second-generation schedule (wkv7_bwd_v5.h); 8: T doubling on the bf16 matrix core
         auto launch5 = [&](auto kern) -> int {
             // the > 64 KB LDS opt-in is per device: set it on every launch (cheap) instead of caching a per-process flag
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -143,7 +154,10 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H, const void* w, const void* q, 
             hipLaunchKernelGGL(kern, grid, dim3(512), sizeof(wkv7v5::LdsV5), st, p);
             return 0;
         };
-        const int e = g_bwd_variant == 8 ? launch5(&wkv7v5::bwd_kernel_v5<false, 2>) : launch5(&wkv7v5::bwd_kernel_v5<false, 0>);
+        const int e = g_bwd_variant == 8 ? launch5(&wkv7v5::bwd_kernel_v5<false, 2>) : g_bwd_variant == 9 ? launch5(&wkv7v5::bwd_kernel_v5<false, 4>)
+                    : g_bwd_variant == 10 ? launch5(&wkv7v5::bwd_kernel_v5<false, 8>) : g_bwd_variant == 11 ? launch5(&wkv7v5::bwd_kernel_v5<false, 6>)
+                    : g_bwd_variant == 12 ? launch5(&wkv7v5::bwd_kernel_v5<false, 10>) : g_bwd_variant == 7 ? launch5(&wkv7v5::bwd_kernel_v5<false, 0>)
+                    : launch5(&wkv7v5::bwd_kernel_v5<false, 6>);
         if (e) return e;
     } else if (g_bwd_variant == 0) {
         hipLaunchKernelGGL((wkv7::bwd_kernel<8>), grid, dim3(256), 0, st, p);
@@ -193,7 +207,7 @@ int vrwkv_wkv7_backward_segments_bf16(int B, int T, int H, int nseg, const void*
     p.ds_in = ds_in; p.ds_out = ds_out; p.nseg = nseg;
     const dim3 grid((unsigned)((long)B * H * nseg));
     if (g_bwd_variant < 0 || g_bwd_variant == 7 || g_bwd_variant == 8) {
-        auto kern = &wkv7v5::bwd_kernel_v5<false, 0, true>;
+        auto kern = &wkv7v5::bwd_kernel_v5<false, 6, true>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)sizeof(wkv7v5::LdsV5));
         if (e != hipSuccess) return (int)e;
@@ -222,7 +236,12 @@ int vrwkv_wkv7_profile_bf16(int backward, int B, int T, int H, const void* w, co
     if (!backward) {
         wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                         (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, s, sa, dbg};
-        if (backward == 0 && g_fwd_variant == 3) {
+        if (g_fwd_variant == 12) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7v5::fwd_kernel_v5<true, 0>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7v5::LdsF5));
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL((wkv7v5::fwd_kernel_v5<true, 0>), grid, dim3(512), sizeof(wkv7v5::LdsF5), st, p);
+        } else if (backward == 0 && g_fwd_variant == 3) {
             hipLaunchKernelGGL(wkv7c::fwd_kernel_t<true>, grid, dim3(256), 0, st, p);
         } else {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::fwd_kernel_v3<true, false, 1>),
@@ -240,10 +259,10 @@ int vrwkv_wkv7_profile_bf16(int backward, int B, int T, int H, const void* w, co
             if (e != hipSuccess) return (int)e;
             hipLaunchKernelGGL((wkv7v5::bwd_kernel_v5<false, 0, false, true>), grid, dim3(512), sizeof(wkv7v5::LdsV5), st, p);
         } else if (g_bwd_variant < 0 || g_bwd_variant == 7 || g_bwd_variant == 8) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7v5::bwd_kernel_v5<true, 0>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7v5::bwd_kernel_v5<true, 6>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7v5::LdsV5));
             if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL((wkv7v5::bwd_kernel_v5<true, 0>), grid, dim3(512), sizeof(wkv7v5::LdsV5), st, p);
+            hipLaunchKernelGGL((wkv7v5::bwd_kernel_v5<true, 6>), grid, dim3(512), sizeof(wkv7v5::LdsV5), st, p);
         } else if (g_bwd_variant == 1) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::bwd_kernel_t<true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsB));

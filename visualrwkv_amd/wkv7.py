@@ -36,8 +36,12 @@ _BWD_SCHEMA = ("backward(Tensor w, Tensor q, Tensor k, Tensor v, Tensor z, Tenso
 # Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).  When
 # `EVENT_LOG` is a list, every op call appends (kind, start_event, end_event, B*T*H*64).
 EVENT_LOG = None
-TPARALLEL_BWD = os.environ.get("VRWKV_TPAR_BWD", "0") == "1"     # sequence-parallel training op for few heads; not the
-                                                                 # default until it has been timed on the GPU
+# Sequence-parallel training op for few heads (B*H workgroups on 256 CUs).  Timed on MI355X (profiles/r2_tpar_micro.jsonl,
+# H = 32): backward 1.52 -> 0.61 ms at B=1, T=6400 (8 segments), 0.61 -> 0.45 ms at B=1, T=2624 (4), 1.53 -> 1.09 / 0.63 -> 0.49 ms
+# at B=2; no gain from B*H = 128 on.  The forward (three passes + a checkpoint re-order) only wins for one sequence of
+# T >= 4096 (0.77 -> 0.48 ms).  VRWKV_TPAR_BWD=0 switches both off, =1 forces them wherever segments() > 1.
+_TPAR_ENV = os.environ.get("VRWKV_TPAR_BWD", "auto")
+TPARALLEL_BWD = _TPAR_ENV != "0"
 
 
 def _timed(kind, elems, stream_dev, fn):
@@ -148,8 +152,8 @@ class WindBackstepping(torch.autograd.Function):
         assert T % CHUNK_LEN == 0
         assert all(i.dtype == torch.bfloat16 for i in [w, q, k, v, z, b])
         assert all(i.is_contiguous() for i in [w, q, k, v, z, b])
-        P = tparallel_segments(B, H, T) if TPARALLEL_BWD and w.is_cuda else 1
-        if P > 1:                                       # opt-in: few heads -> sequence-parallel forward (and backward)
+        P = tparallel_segments(B, H, T, forward=True) if TPARALLEL_BWD and w.is_cuda else 1
+        if P > 1:                                       # one long sequence: sequence-parallel forward
             y, _, s, sa = wkv7_forward_tparallel(w, q, k, v, z, b, segments=P, train=True)
         else:
             y = torch.empty_like(v)
@@ -164,7 +168,7 @@ class WindBackstepping(torch.autograd.Function):
         assert all(i.dtype == torch.bfloat16 for i in [dy])
         assert all(i.is_contiguous() for i in [dy])
         w, q, k, v, z, b, s, sa = ctx.saved_tensors
-        if TPARALLEL_BWD and w.is_cuda:                 # opt-in (VRWKV_TPAR_BWD=1): few heads -> sequence-parallel backward
+        if TPARALLEL_BWD and w.is_cuda:                 # few heads -> sequence-parallel backward
             B, T, H, _ = w.shape
             P = tparallel_segments(B, H, T)
             if P > 1:
@@ -218,10 +222,14 @@ def wkv7_prefill(w, q, k, v, z, a, state0=None):
     return wkv7_forward_state(w, q, k, v, z, a, state0, want_state=True)
 
 
-def tparallel_segments(B, H, T, n_cu=256, max_segments=16):
+def tparallel_segments(B, H, T, n_cu=256, max_segments=16, forward=False):
     """How many T-segments to cut a sequence into so that B*H*segments workgroups fill the chip:
-    1 when the heads alone fill it or the sequence is too short to amortise the three passes."""
+    1 when the heads alone fill it or the sequence is too short to amortise the extra passes.  With the measured
+    defaults (VRWKV_TPAR_BWD unset) the backward is cut when B*H <= 64 and T >= 1024, the forward when B*H <= 32 and
+    T >= 4096; VRWKV_TPAR_BWD=1 cuts whenever at least 3 segments fit."""
     if B * H >= n_cu or T < 256:
+        return 1
+    if _TPAR_ENV == "auto" and (B * H > (32 if forward else 64) or T < (4096 if forward else 1024)):
         return 1
     p = min(max_segments, max(1, n_cu // (B * H)), T // 64)
     while p > 1 and (T % p != 0 or (T // p) % CHUNK_LEN != 0):
