@@ -7,6 +7,11 @@ ew = -exp(w.float()); gu is summed over the batch in Python; gw is the gradient 
 Per head (N = 64), state S[i][j] (i = value index = the reference's thread, j = key index), decay d_t = exp(ew_t):
     y_t[i] = sum_j r_t[j] (u[j] k_t[j] v_t[i] + S[i][j])          S[i][j] <- S[i][j] d_t[j] + k_t[j] v_t[i]
 
+Pinning: tests/golden/make_golden_wkv6.py executes the reference's own pure-PyTorch statement of the recurrence
+(`naive_recurrent_rwkv6_fla`, VisualRWKV-v6/v6.xx/test_kernel.py:175-215, cross-checked against the demo app's CPU loop
+VisualRWKV-v7/v7.00/app/modeling_rwkv.py:891-897) in fp64 and stores inputs, outputs, final state and autograd gradients;
+tests/test_v6_cpu.py::test_oracle_reproduces_the_references_own_recurrence holds `wkv6_naive` to those numbers at 1e-12.
+
 `wkv6_naive` is that recurrence vectorised over (B,H) in any float dtype; gradients come from autograd through it
 (the reference's three backward sweeps are the hand-derived form of exactly this; `wkv6_backward_ref` restates them
 literally for small cases).  `wkv6_chunked` is the 16-token chunk formulation the HIP kernels use, with a pluggable

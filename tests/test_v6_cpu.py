@@ -17,6 +17,34 @@ def gold():
     return torch.load(GOLD)
 
 
+NAIVE_GOLD = os.path.join(os.path.dirname(__file__), "golden", "wkv6_naive_ref.pt")
+
+
+def test_oracle_reproduces_the_references_own_recurrence():
+    """PIN: tests/golden/wkv6_naive_ref.pt holds what the reference's pure-PyTorch `naive_recurrent_rwkv6_fla`
+    (VisualRWKV-v6/v6.xx/test_kernel.py:175-215, cross-checked against app/modeling_rwkv.py:891-897) computes in fp64 on the
+    reference test's own input distributions, with autograd gradients of the reference's LOSS.  The oracle must give the
+    same numbers to fp64 rounding: output, final state (the reference keeps it as [key][value]), all five gradients,
+    with and without an initial state."""
+    g = torch.load(NAIVE_GOLD)
+    assert "naive_recurrent_rwkv6_fla" in g["provenance"]
+    B, T, H, N = g["B"], g["T"], g["H"], g["N"]
+    f = lambda x: x.view(B, T, H, N)
+    for tag in ("zero_state", "with_state"):
+        c = g[tag]
+        ins = [x.clone().requires_grad_(True) for x in (f(g["r"]), f(g["k"]), f(g["v"]), f(g["w"]), g["u"])]
+        s0 = c["s0"].transpose(-1, -2).clone().requires_grad_(True) if c["s0"] is not None else None   # oracle state: [value][key]
+        y, S = wkv6_naive(*ins, state0=s0)
+        y.backward(f(c["gy"]))
+        assert rel_rms(y.detach().reshape(B, T, H * N), c["y"]) < 1e-12
+        assert rel_rms(S.detach().transpose(-1, -2), c["final_state"]) < 1e-12
+        for x, n in zip(ins, ("gr", "gk", "gv", "gw", "gu")):
+            assert rel_rms(x.grad.reshape(c[n].shape), c[n]) < 1e-12, (tag, n)
+        if s0 is not None:
+            # (the reference adds the initial state into an fp32 buffer, `h += initial_state`: its gradient is fp32-rounded)
+            assert rel_rms(s0.grad.transpose(-1, -2), c["gs0"]) < 1e-7
+
+
 def test_literal_backward_kernels_equal_autograd():
     """kernel_backward_111 / _222 (wkv6_cuda.cu:64-227) restated literally == autograd through the forward recurrence."""
     B, T, H, N = 2, 21, 2, 8

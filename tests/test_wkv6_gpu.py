@@ -51,6 +51,21 @@ def test_strong_decays_stay_finite():
     assert rel_rms(grads[3].double(), g_ref[3].reshape(1, 64, 128)) < 6e-3
 
 
+def test_reference_recurrence_fixture():
+    """The HIP op against the fixture computed by the REFERENCE'S OWN pure-PyTorch recurrence
+    (tests/golden/make_golden_wkv6.py: VisualRWKV-v6/v6.xx/test_kernel.py:175-215 executed unmodified in fp64), on the
+    reference test's input distributions (w_raw in [-8, 1]); bf16 outputs on our side."""
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "wkv6_naive_ref.pt"))
+    B, T, H, N = g["B"], g["T"], g["H"], g["N"]
+    f = lambda x: x.view(B, T, H, N).bfloat16()
+    c = g["zero_state"]
+    y, (gr, gk, gv, gw, gu) = _run(f(g["r"]), f(g["k"]), f(g["v"]), g["w"].view(B, T, H, N).float(), g["u"].bfloat16(), f(c["gy"]))
+    assert rel_rms(y.double(), c["y"]) < 6e-3
+    for a, n in ((gr, "gr"), (gk, "gk"), (gv, "gv"), (gw, "gw")):
+        assert rel_rms(a.double().reshape(c[n].shape), c[n]) < 8e-3, n
+    assert rel_rms(gu.double(), c["gu"]) < 1.5e-2
+
+
 def test_reference_wrapper_fixture(gold):
     op = gold["op"]
     B, T, C = op["r"].shape
