@@ -230,6 +230,14 @@ int vrwkv_adamw_step_bf16(long n, float* master, float* m, float* v, const void*
                           float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                           float grad_scale, long global_offset, long wd_boundary, void* stream);
 
+/* The same step with the clip factor formed on the device: sqnorm[0] = squared L2 norm of the (unscaled, summed over
+ * ranks) gradient, grad scale = inv_world * min(1, clip / (sqrt(sqnorm) * inv_world + 1e-6)) (clip <= 0: no clipping).
+ * Replaces Lightning's gradient_clip_val=1.0 host-side norm (train.py:92) without a device -> host synchronisation. */
+int vrwkv_adamw_step_clip_bf16(long n, float* master, float* m, float* v, const void* grad, void* param,
+                               float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                               const float* sqnorm, float inv_world, float clip, long global_offset, long wd_boundary,
+                               void* stream);
+
 /* out[0] += sum of squares of a bf16 buffer (n % 8 == 0); used for gradient_clip_val=1.0 (train.py:92). */
 int vrwkv_sqnorm_bf16(long n, const void* x, float* out, void* stream);
 

@@ -128,3 +128,30 @@ def test_schedule_and_sampler_match_reference_formulas():
     assert largest_3n_plus_2_prime(665298) == 665279 and largest_3n_plus_2_prime(10) == 5
     idx, rev = rank_strided_sample(0, 3, 1, 8, 8000, 665279)
     assert idx == (25 ** 3) % 665279 and rev is False
+
+
+def test_buckets_are_reduced_in_index_order_whatever_order_gradients_arrive():
+    """NCCL pairs collectives by issue order: every rank must reduce bucket 0, 1, 2, ... even when its own gradients
+    complete the buckets in another order (e.g. a rank whose batch has no image placeholder gets no `proj` gradient)."""
+    from visualrwkv_amd.dp import Zero1Engine
+    orders = []
+    for perm_seed in (0, 1, 2):
+        torch.manual_seed(0)
+        m = _model()
+        eng = Zero1Engine(m, lr=1e-2, weight_decay=0.0, grad_clip=0.0, bucket_mb=0.0005)
+        assert len(eng.buckets) >= 4
+        launched = []
+        eng._launch_reduce = lambda b, rec=launched, e=eng: rec.append(e.buckets.index(b))
+        eng.zero_grad(set_to_none=False)
+        g = torch.Generator().manual_seed(perm_seed)
+        order = torch.randperm(len(eng.params), generator=g).tolist()
+        skip = order[0] if perm_seed == 2 else None            # one parameter without gradient on this "rank"
+        for k in order:
+            if k == skip:
+                continue
+            eng.params[k].grad = eng._view(k)
+            eng._hooks[k]  # (hooks are registered; call the hook body directly)
+            eng._make_hook(k)(eng.params[k])
+        eng.step()
+        orders.append(launched)
+    assert all(o == list(range(len(o))) for o in orders) and len({len(o) for o in orders}) == 1

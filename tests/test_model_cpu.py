@@ -182,3 +182,43 @@ def test_dinov2_reg_against_transformers():
         got = mine(x)
     assert got.shape == (2, 16, 64)
     assert rel_rms(got, ref) < 1e-5
+
+
+def test_vision_tower_checkpoints_load_or_fail_loudly(tmp_path):
+    """`vision_tower_path` (vision.py:58-70, sam.py:498-505): timm-format files with a different pretraining grid and the
+    pooling-head keys, a SAM file with the `image_encoder.` prefix and foreign keys; a missing file or a foreign checkpoint
+    is an error, never a silent random-weight tower."""
+    from visualrwkv_amd.vit import SamDinoSigLIPViTBackbone, SamImageEncoder, TimmViT
+    torch.manual_seed(0)
+    kw = {"dino": dict(depth=2, dim=32, heads=2), "siglip": dict(depth=2, dim=32, heads=2, mlp_hidden=48),
+          "sam": dict(img_size=64, dim=32, depth=2, heads=2, out_chans=8, window=2, global_attn_indexes=(1,))}
+    src_dino = TimmViT(42, 14, 32, 2, 2, 128, class_token=True, reg_tokens=4, ls_init=1e-5)      # 3x3 grid "pretraining" size
+    src_sig = TimmViT(70, 14, 32, 2, 2, 48, class_token=False, reg_tokens=0, ls_init=None)       # 5x5 grid
+    src_sam = SamImageEncoder(**kw["sam"])
+    with torch.no_grad():
+        for m in (src_dino, src_sig, src_sam):
+            for p in m.parameters():
+                p.normal_(0, 0.1)
+    sd_sig = dict(src_sig.state_dict())
+    sd_sig["attn_pool.q.weight"] = torch.zeros(3, 3)
+    sd_sig["fc_norm.weight"] = torch.zeros(3)
+    torch.save(src_dino.state_dict(), tmp_path / "dino.pth")
+    torch.save(sd_sig, tmp_path / "siglip.bin")
+    sam_sd = {"image_encoder." + k: v for k, v in src_sam.state_dict().items()}
+    sam_sd["mask_decoder.foo"] = torch.zeros(2)
+    torch.save(sam_sd, tmp_path / "sam.pth")
+    paths = {"dino": str(tmp_path / "dino.pth"), "siglip": str(tmp_path / "siglip.bin"), "sam": str(tmp_path / "sam.pth")}
+    bb = SamDinoSigLIPViTBackbone(paths, default_image_size=56, tower_kwargs=kw)                 # 4x4 grid here
+    assert torch.equal(bb.dino_featurizer.blocks[1].attn.qkv.weight, src_dino.blocks[1].attn.qkv.weight)
+    assert torch.equal(bb.siglip_featurizer.patch_embed.proj.weight, src_sig.patch_embed.proj.weight)
+    assert bb.dino_featurizer.pos_embed.shape == (1, 16, 32) and bb.siglip_featurizer.pos_embed.shape == (1, 16, 32)
+    ref = torch.nn.functional.interpolate(src_sig.pos_embed.reshape(1, 5, 5, 32).permute(0, 3, 1, 2), size=(4, 4), mode="bicubic",
+                                          antialias=True).permute(0, 2, 3, 1).reshape(1, 16, 32)
+    assert torch.allclose(bb.siglip_featurizer.pos_embed, ref)
+    assert torch.equal(bb.sam_featurizer.blocks[0].attn.rel_pos_h, src_sam.blocks[0].attn.rel_pos_h)
+    with pytest.raises(FileNotFoundError):
+        SamDinoSigLIPViTBackbone({**paths, "sam": str(tmp_path / "nope.pth")}, default_image_size=56, tower_kwargs=kw)
+    with pytest.raises(RuntimeError):
+        SamDinoSigLIPViTBackbone({**paths, "dino": paths["siglip"]}, default_image_size=56, tower_kwargs=kw)
+    with pytest.raises(KeyError):
+        SamDinoSigLIPViTBackbone({"dino": paths["dino"]}, default_image_size=56, tower_kwargs=kw)

@@ -16,7 +16,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(long n, float* __restrict__ 
                                                     float* __restrict__ v, const uint16_t* __restrict__ grad,
                                                     uint16_t* __restrict__ param, float lr, float b1, float b2, float eps,
                                                     float wd, float inv_bc1, float inv_sqrt_bc2, float grad_scale,
-                                                    long global_offset, long wd_boundary) {
+                                                    long global_offset, long wd_boundary, const float* __restrict__ sqnorm,
+                                                    float clip) {
+    // sqnorm != nullptr: the global squared gradient norm lives on the device (summed over ranks, of the UNSCALED
+    // gradient sum); the clip factor min(1, clip / (|g| + 1e-6)) is formed here instead of on the host, so the
+    // optimizer step needs no device -> host synchronisation.  grad_scale then is 1 / world.
+    if (sqnorm) {
+        const float gnorm = sqrtf(*sqnorm) * grad_scale;
+        if (clip > 0.f) grad_scale *= fminf(1.f, clip / (gnorm + 1e-6f));
+    }
     const long nvec = n >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
         float4 p4 = reinterpret_cast<float4*>(master)[i];
@@ -74,7 +82,21 @@ int vrwkv_adamw_step_bf16(long n, float* master, float* m, float* v, const void*
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, (hipStream_t)stream, n, master, m, v,
                        (const uint16_t*)grad, (uint16_t*)param, lr, beta1, beta2, eps, weight_decay,
-                       (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale, global_offset, wd_boundary);
+                       (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale, global_offset, wd_boundary, (const float*)nullptr, 0.f);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? VRWKV_OK : (int)e;
+}
+
+int vrwkv_adamw_step_clip_bf16(long n, float* master, float* m, float* v, const void* grad, void* param,
+                               float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                               const float* sqnorm, float inv_world, float clip, long global_offset, long wd_boundary,
+                               void* stream) {
+    if (n <= 0 || !master || !m || !v || !grad || !param || !sqnorm || step < 1) return VRWKV_EINVAL;
+    if (n % 4 != 0) return VRWKV_ESHAPE;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, (hipStream_t)stream, n, master, m, v,
+                       (const uint16_t*)grad, (uint16_t*)param, lr, beta1, beta2, eps, weight_decay,
+                       (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), inv_world, global_offset, wd_boundary, sqnorm, clip);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? VRWKV_OK : (int)e;
 }

@@ -19,7 +19,7 @@ MAX_B = 4
 
 
 def _stream(dev):
-    return torch.cuda.current_stream(dev).cuda_stream
+    return hip_lib.launch_stream(dev)
 
 
 def gemv_multi(jobs, B, device):
@@ -111,7 +111,8 @@ def tmix_head(m, r, k, v, v_first, hidden, S, carry=None):
 
 def _transposed(m, names, slot="_decode_cache"):
     """(N,K)-major copies of the LoRA factors used as `x @ p`; cached on the module, keyed by the parameters' versions."""
-    key = tuple((getattr(m, n).data_ptr(), getattr(m, n)._version) for n in names)
+    from . import param_state
+    key = (param_state.generation(),) + tuple((getattr(m, n).data_ptr(), getattr(m, n)._version) for n in names)
     cache = getattr(m, slot, None)
     if cache is None or cache[0] != key:
         cache = (key, {n: getattr(m, n).detach().t().contiguous() for n in names})

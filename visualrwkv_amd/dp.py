@@ -55,7 +55,7 @@ def lr_wd_schedule(real_step: int, lr_init: float, lr_final: float, warmup_steps
 
 
 class _Bucket:
-    __slots__ = ("start", "end", "piece", "pending", "n_params", "master", "m", "v", "work", "event", "param_ids")
+    __slots__ = ("start", "end", "piece", "pending", "n_params", "master", "m", "v", "work", "event", "param_ids", "launched")
 
 
 class Zero1Engine:
@@ -78,11 +78,17 @@ class Zero1Engine:
         self.dtype = params[0].dtype
         self.on_gpu = self.device.type == "cuda"
         self.overlap = overlap and self.on_gpu and self.collective
-        wd = [p for p in params if len(p.squeeze().shape) >= 2]
-        nowd = [p for p in params if len(p.squeeze().shape) < 2]
-        # later layers produce their gradients first: lay the flat buffer out in reverse registration order
-        # inside each group so that buckets fill front to back during the backward
-        ordered = wd[::-1] + nowd[::-1]
+        # Lay the flat buffer out in the order the backward produces the gradients, so that buckets fill front to back:
+        # reverse registration order for the language model (head, blocks N-1 .. 0), and whatever feeds the language model's
+        # INPUT (the image projector `proj`, the embedding) last -- their gradients only exist when the backward has walked
+        # the whole stack.  (Plain reverse registration order put `proj`, which is registered last, at the front of bucket 0
+        # and kept that bucket from being reduced until the very end of the backward.)
+        names = {id(p): n for n, p in model.named_parameters()}
+        late = lambda p: names.get(id(p), "").startswith(("proj.", "rwkv.emb.", "emb."))
+        by_ready = [p for p in params[::-1] if not late(p)] + [p for p in params[::-1] if late(p)]
+        wd = [p for p in by_ready if len(p.squeeze().shape) >= 2]
+        nowd = [p for p in by_ready if len(p.squeeze().shape) < 2]
+        ordered = wd + nowd
         align = 8 * self.world                       # every piece 16-byte aligned in bf16
         offs, total = [], 0
         for p in ordered:
@@ -112,7 +118,7 @@ class Zero1Engine:
             b.master = self.flat_param[ps:ps + b.piece].float().clone()
             b.m = torch.zeros_like(b.master)
             b.v = torch.zeros_like(b.master)
-            b.n_params, b.pending, b.work, b.event = 0, 0, None, None
+            b.n_params, b.pending, b.work, b.event, b.launched = 0, 0, None, None, False
             b.param_ids = []
             self.buckets.append(b)
             s = b.end
@@ -139,14 +145,25 @@ class Zero1Engine:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(k)))
         self._sq = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._gather = False
+        self._next_launch = 0
+        self._gather_event = None
+        self.generation = 0
+        self._wait_hooks = []
+        if self.collective and self.on_gpu:
+            # the parameter all-gather runs on the side stream; whoever first touches a trainable parameter in the next
+            # forward waits for it (the frozen ViT encode ahead of the projector overlaps with it)
+            for mod in model.modules():
+                if any(p.requires_grad for p in mod.parameters(recurse=False)):
+                    self._wait_hooks.append(mod.register_forward_pre_hook(lambda m, a: self.wait_params()))
         self._reset_pending()
 
     # ------------------------------------------------------------------ gradient reduction
     def _reset_pending(self):
         for b in self.buckets:
             b.pending = b.n_params
-            b.work, b.event = None, None
+            b.work, b.event, b.launched = None, None, False
         self._fired = [False] * len(self.params)
+        self._next_launch = 0
 
     def _view(self, k):
         o, p = self.offsets[k], self.params[k]
@@ -160,12 +177,21 @@ class Zero1Engine:
                 self._stash[k] = g                   # autograd handed over a fresh tensor: copied bucket-wise
             self._fired[k] = True
             for i in self._param_buckets[k]:
-                b = self.buckets[i]
-                b.pending -= 1
-                if b.pending == 0:
-                    self._flush(b)
-                    self._launch_reduce(b)
+                self.buckets[i].pending -= 1
+            self._launch_ready()
         return hook
+
+    def _launch_ready(self):
+        """Reduce complete buckets strictly in index order: every rank issues the same sequence of collectives, whatever
+        order its own gradients arrive in (a rank whose batch leaves a parameter without gradient -- e.g. no image
+        placeholder, so no `proj` gradient -- completes that bucket only in step(), and must not overtake it with later
+        buckets: NCCL pairs collectives by issue order)."""
+        while self._next_launch < len(self.buckets) and self.buckets[self._next_launch].pending == 0:
+            b = self.buckets[self._next_launch]
+            self._flush(b)
+            self._launch_reduce(b)
+            b.launched = True
+            self._next_launch += 1
 
     @torch.no_grad()
     def _flush(self, b: _Bucket):
@@ -219,16 +245,18 @@ class Zero1Engine:
         the updated bf16 parameters.  Returns the pre-clip global gradient norm."""
         lr = self.lr if lr is None else lr
         self.step_count += 1
-        for b in self.buckets:                       # buckets whose hooks never all fired (unused parameters)
-            if b.pending > 0:
-                self._flush(b)
-                if self._gather:
-                    for k in b.param_ids:
-                        if not self._fired[k]:
-                            v = self._view(k)
-                            v.zero_()
-                            self.params[k].grad = v
-                self._launch_reduce(b)
+        self.wait_params()
+        for b in self.buckets[self._next_launch:]:   # in index order: buckets whose hooks never all fired (unused parameters)
+            self._flush(b)
+            if b.pending > 0 and self._gather:
+                for k in b.param_ids:
+                    if not self._fired[k]:
+                        v = self._view(k)
+                        v.zero_()
+                        self.params[k].grad = v
+            self._launch_reduce(b)
+            b.launched = True
+        self._next_launch = len(self.buckets)
         if self.collective:
             if self.overlap:
                 for b in self.buckets:
@@ -242,23 +270,47 @@ class Zero1Engine:
             self._sqnorm(g, self._sq)
         if self.collective:
             dist.all_reduce(self._sq, group=self.pg)
-        gnorm = float(self._sq.sqrt()) * inv_world
-        scale = inv_world
-        if self.grad_clip and self.grad_clip > 0:
-            scale *= min(1.0, self.grad_clip / (gnorm + 1e-6))
-        for b in self.buckets:
-            self._adamw(b, lr, scale)
-        if self.collective:
+        clip = float(self.grad_clip) if self.grad_clip and self.grad_clip > 0 else 0.0
+        if self.on_gpu and self.dtype == torch.bfloat16:
+            for b in self.buckets:               # clip factor formed on the device from self._sq: no host synchronisation
+                self._adamw(b, lr, None, inv_world, clip)
+            gnorm = self._sq.sqrt() * inv_world   # device tensor (float(gnorm) synchronises; the step itself does not)
+        else:
+            gnorm = float(self._sq.sqrt()) * inv_world
+            scale = inv_world * (min(1.0, clip / (gnorm + 1e-6)) if clip > 0 else 1.0)
             for b in self.buckets:
-                buf = self.flat_param[b.start:b.end]
-                piece = buf[self.rank * b.piece:(self.rank + 1) * b.piece]
-                if dist.get_backend(self.pg) == "nccl":
-                    dist.all_gather_into_tensor(buf, piece, group=self.pg)          # in place (own slot = input)
-                else:   # gloo (CPU tests): bit-cast to int16, list form
-                    raw = buf.view(torch.int16) if buf.dtype == torch.bfloat16 else buf
-                    dist.all_gather(list(raw.chunk(self.world)), raw[self.rank * b.piece:(self.rank + 1) * b.piece].clone(), group=self.pg)
+                self._adamw(b, lr, scale, inv_world, clip)
+        if self.collective:
+            if self.overlap:                      # publish on the side stream; the next forward waits where it needs them
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream(self.device))
+                self.comm_stream.wait_event(done)
+                with torch.cuda.stream(self.comm_stream):
+                    self._all_gather()
+                    self._gather_event = torch.cuda.Event()
+                    self._gather_event.record(self.comm_stream)
+            else:
+                self._all_gather()
+        from . import param_state
+        self.generation = param_state.bump()      # decode caches (transposed factors, captured graphs) key on this
         self._reset_pending()
         return gnorm
+
+    def _all_gather(self):
+        for b in self.buckets:
+            buf = self.flat_param[b.start:b.end]
+            piece = buf[self.rank * b.piece:(self.rank + 1) * b.piece]
+            if dist.get_backend(self.pg) == "nccl":
+                dist.all_gather_into_tensor(buf, piece, group=self.pg)          # in place (own slot = input)
+            else:   # gloo (CPU tests): bit-cast to int16, list form
+                raw = buf.view(torch.int16) if buf.dtype == torch.bfloat16 else buf
+                dist.all_gather(list(raw.chunk(self.world)), raw[self.rank * b.piece:(self.rank + 1) * b.piece].clone(), group=self.pg)
+
+    def wait_params(self):
+        """Make the current stream wait for the parameter all-gather of the last step (no-op when none is pending)."""
+        ev, self._gather_event = self._gather_event, None
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
 
     def zero_grad(self, set_to_none: bool = True):
         """set_to_none (default): detach `.grad` so that the next backward hands its gradient tensors over instead
@@ -280,23 +332,29 @@ class Zero1Engine:
     def _sqnorm(self, g, out):
         if self.on_gpu and g.dtype == torch.bfloat16 and g.numel() % 8 == 0:
             from . import hip_lib
-            rc = hip_lib.load().vrwkv_sqnorm_bf16(g.numel(), g.data_ptr(), out.data_ptr(),
-                                                  torch.cuda.current_stream(self.device).cuda_stream)
+            rc = hip_lib.load().vrwkv_sqnorm_bf16(g.numel(), g.data_ptr(), out.data_ptr(), hip_lib.launch_stream(self.device))
             hip_lib.check(rc, "vrwkv_sqnorm_bf16")
         else:
             out += g.float().pow(2).sum()
 
-    def _adamw(self, b: _Bucket, lr, scale):
+    def _adamw(self, b: _Bucket, lr, scale, inv_world=1.0, clip=0.0):
         g = self._piece(self.flat_grad, b)
         p = self._piece(self.flat_param, b)
         off = b.start + self.rank * b.piece
         b1, b2 = self.betas
         if self.on_gpu and g.dtype == torch.bfloat16:
             from . import hip_lib
+            st = hip_lib.launch_stream(self.device)
+            if scale is None:
+                rc = hip_lib.load().vrwkv_adamw_step_clip_bf16(
+                    b.piece, b.master.data_ptr(), b.m.data_ptr(), b.v.data_ptr(), g.data_ptr(), p.data_ptr(),
+                    lr, b1, b2, self.eps, self.weight_decay, self.step_count, self._sq.data_ptr(), inv_world, clip, off,
+                    self.wd_boundary, st)
+                hip_lib.check(rc, "vrwkv_adamw_step_clip_bf16")
+                return
             rc = hip_lib.load().vrwkv_adamw_step_bf16(
                 b.piece, b.master.data_ptr(), b.m.data_ptr(), b.v.data_ptr(), g.data_ptr(), p.data_ptr(),
-                lr, b1, b2, self.eps, self.weight_decay, self.step_count, scale, off, self.wd_boundary,
-                torch.cuda.current_stream(self.device).cuda_stream)
+                lr, b1, b2, self.eps, self.weight_decay, self.step_count, scale, off, self.wd_boundary, st)
             hip_lib.check(rc, "vrwkv_adamw_step_bf16")
             return
         # host restatement of the kernel (CPU tests of the distributed logic)

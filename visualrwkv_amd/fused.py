@@ -18,7 +18,7 @@ from .wkv7 import RUN_CUDA_RWKV7g
 
 
 def _stream(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return hip_lib.launch_stream(t.device)
 
 
 def _chk(*ts):

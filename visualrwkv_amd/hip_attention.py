@@ -23,6 +23,6 @@ def flash_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Te
     o = torch.empty(B, L, H, D, dtype=q.dtype, device=q.device)
     sb, sl, sh, _ = q.stride()
     rc = hip_lib.load().vrwkv_attention_fwd_bf16(B, L, H, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), sb, sl, sh,
-                                                 o.data_ptr(), torch.cuda.current_stream(q.device).cuda_stream)
+                                                 o.data_ptr(), hip_lib.launch_stream(q.device))
     hip_lib.check(rc, "vrwkv_attention_fwd_bf16")
     return o

@@ -52,6 +52,7 @@ PROTOTYPES = {
     "vrwkv_relusq_bwd_bf16": (_c_int, [ctypes.c_long] + [_c_void_p] * 4),
     "vrwkv_attention_fwd_bf16": (_c_int, [_c_int] * 4 + [_c_void_p] * 3 + [ctypes.c_long] * 3 + [_c_void_p] * 2),
     "vrwkv_adamw_step_bf16": (_c_int, [ctypes.c_long] + [_c_void_p] * 5 + [ctypes.c_float] * 5 + [_c_int, ctypes.c_float, ctypes.c_long, ctypes.c_long, _c_void_p]),
+    "vrwkv_adamw_step_clip_bf16": (_c_int, [ctypes.c_long] + [_c_void_p] * 5 + [ctypes.c_float] * 5 + [_c_int, _c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_long, ctypes.c_long, _c_void_p]),
     "vrwkv_sqnorm_bf16": (_c_int, [ctypes.c_long, _c_void_p, _c_void_p, _c_void_p]),
     "vrwkv_wkv7_profile_bf16": (_c_int, [_c_int] * 4 + [_c_void_p] * 18),
     "vrwkv_wgrad_skinny_ws_floats": (_c_long, [_c_long, _c_int, _c_int]),
@@ -91,3 +92,16 @@ def check(code: int, what: str) -> None:
     if code != 0:
         msg = load().vrwkv_strerror(code).decode()
         raise RuntimeError(f"{what} failed: {msg} (code {code})")
+
+
+def launch_stream(device) -> int:
+    """Raw handle of PyTorch's current stream on `device` for a ctypes launch.  The kernels are launched on that stream,
+    which belongs to `device`: HIP requires it to be the calling thread's current device (one process per GPU always is).
+    Anything else is a caller error and is reported instead of launching on the wrong device (wkv7.py / wkv6.py wrap their
+    launches in `torch.cuda.device(...)` because the reference's op surface accepts tensors of any device)."""
+    import torch
+    dev = torch.device(device)
+    if dev.index is not None and dev.index != torch.cuda.current_device():
+        raise RuntimeError(f"visualrwkv_amd: tensors live on {dev} but the current device is cuda:{torch.cuda.current_device()}; "
+                           f"wrap the call in `with torch.cuda.device({dev.index}):`")
+    return torch.cuda.current_stream(dev).cuda_stream

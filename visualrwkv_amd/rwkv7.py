@@ -351,7 +351,8 @@ class RWKV(nn.Module):
         versions); later calls copy `state` into the graph's own state tensors.  The returned decoder advances ITS
         state (`decoder.state`), not the argument."""
         S0 = state.S[0]
-        key = (S0.shape[0], S0.device, sum(p._version for p in self.parameters()))
+        from . import param_state
+        key = (S0.shape[0], S0.device, sum(p._version for p in self.parameters()), param_state.generation())
         cache = self.__dict__.setdefault("_decoders", {})
         dec = cache.get(key)
         if dec is None:

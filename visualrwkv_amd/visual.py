@@ -107,8 +107,9 @@ class VisualRWKV(nn.Module):
         selected = samples["input_ids"].view(B * Ln) == IMAGE_TOKEN_INDEX
         n_sel = int(selected.sum()) if getattr(self.args, "check_image_tokens", True) else image_features.shape[0]
         if n_sel != image_features.shape[0]:
+            n_feat = image_features.shape[0]
             image_features = image_features[:n_sel]      # the reference truncates and warns (model.py:487-491)
-            warnings.warn(f"image tokens: {n_sel}, but image features: {image_features.shape[0]}")
+            warnings.warn(f"image tokens: {n_sel}, but image features: {n_feat}")
         input_embeds = input_embeds.masked_scatter(selected[:, None], image_features.to(input_embeds.dtype))
         return input_embeds.view(B, Ln, D), samples["labels"]
 

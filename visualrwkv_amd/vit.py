@@ -263,6 +263,78 @@ class SamImageEncoder(nn.Module):
         return x.permute(0, 3, 1, 2)
 
 
+# ------------------------------------------------------------------------------------------------
+# Pretrained tower files (vision.py:58-70: timm `pretrained_cfg_overlay=dict(file=...)`; sam.py:498-505)
+# ------------------------------------------------------------------------------------------------
+_TIMM_IGNORED = ("attn_pool.", "fc_norm.", "head.", "mask_token")     # dropped by timm for num_classes=0 / never used by
+                                                                      # get_intermediate_layers (SigLIP's pooling head)
+
+
+def _read_checkpoint(path: str) -> Dict[str, torch.Tensor]:
+    if not isinstance(path, (str, bytes)) or not path or not __import__("os").path.exists(path):
+        raise FileNotFoundError(f"vision tower checkpoint not found: {path!r}")
+    if str(path).endswith(".safetensors"):
+        from safetensors.torch import load_file
+        sd = load_file(path)
+    else:
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+    for key in ("state_dict", "model"):                      # common wrappers
+        if isinstance(sd, dict) and key in sd and isinstance(sd[key], dict):
+            sd = sd[key]
+    return sd
+
+
+def _resample_pos_embed(pe: torch.Tensor, grid: int, num_prefix: int) -> torch.Tensor:
+    """timm `resample_abs_pos_embed`: the grid part of a learned position embedding to `grid` x `grid` (bicubic,
+    antialias), prefix tokens kept.  pe: (1, P + g*g, D)."""
+    if pe.shape[1] == num_prefix + grid * grid:
+        return pe
+    prefix, body = pe[:, :num_prefix], pe[:, num_prefix:]
+    g0 = int(round(body.shape[1] ** 0.5))
+    if g0 * g0 != body.shape[1]:
+        raise ValueError(f"position embedding with {body.shape[1]} grid entries is not square")
+    body = body.reshape(1, g0, g0, -1).permute(0, 3, 1, 2).float()
+    body = F.interpolate(body, size=(grid, grid), mode="bicubic", antialias=True, align_corners=False)
+    body = body.permute(0, 2, 3, 1).reshape(1, grid * grid, -1).to(pe.dtype)
+    return torch.cat([prefix, body], dim=1) if num_prefix else body
+
+
+def load_timm_vit(model: "TimmViT", path: str) -> None:
+    """Load a timm VisionTransformer checkpoint (DINOv2-reg4 / SigLIP-so400m) into the restated tower: pooling-head keys
+    are ignored, the position embedding is resampled to this tower's grid (timm does the same when `img_size` differs from
+    the pretraining size: 37x37 or 27x27 -> 32x32 at 448), everything else must match exactly."""
+    sd = {k: v for k, v in _read_checkpoint(path).items() if not k.startswith(_TIMM_IGNORED)}
+    if "pos_embed" in sd:
+        pe = sd["pos_embed"]
+        # DINOv2-reg (no_embed_class) stores grid entries only; plain class-token ViTs store 1 + g*g
+        n_grid = model.grid * model.grid
+        extra = pe.shape[1] - int(round((pe.shape[1]) ** 0.5)) ** 2
+        num_prefix = extra if extra in (0, 1) and pe.shape[1] != n_grid else 0
+        pe = _resample_pos_embed(pe, model.grid, num_prefix)
+        sd["pos_embed"] = pe[:, num_prefix:] if num_prefix else pe
+    own = model.state_dict()
+    missing, unexpected = sorted(set(own) - set(sd)), sorted(set(sd) - set(own))
+    if missing or unexpected:
+        raise RuntimeError(f"{path}: not a checkpoint of this tower (missing {missing[:5]}, unexpected {unexpected[:5]})")
+    for k, v in sd.items():
+        if tuple(v.shape) != tuple(own[k].shape):
+            raise RuntimeError(f"{path}: {k} has shape {tuple(v.shape)}, the tower expects {tuple(own[k].shape)}")
+    model.load_state_dict(sd, strict=True)
+
+
+def load_sam_encoder(model: "SamImageEncoder", path: str) -> None:
+    """SAM checkpoint -> image encoder (src/sam.py:498-505: keys under `image_encoder.`; prompt encoder / mask decoder
+    ignored).  Unlike the reference (strict=False + a printed message) a key or shape mismatch is an error."""
+    sd = _read_checkpoint(path)
+    if any(k.startswith("image_encoder.") for k in sd):
+        sd = {k[len("image_encoder."):]: v for k, v in sd.items() if k.startswith("image_encoder.")}
+    own = model.state_dict()
+    missing = sorted(set(own) - set(sd))
+    if missing:
+        raise RuntimeError(f"{path}: SAM image-encoder keys missing: {missing[:5]}")
+    model.load_state_dict({k: sd[k] for k in own}, strict=True)
+
+
 class SamDinoSigLIPViTBackbone(nn.Module):
     """vision.py:49-145 without the PIL/timm transform plumbing (pixel tensors come in pre-processed).
     `towers` selects which encoders exist; the concatenation order is dino, siglip, sam (vision.py:134)."""
@@ -278,6 +350,12 @@ class SamDinoSigLIPViTBackbone(nn.Module):
             self.siglip_featurizer = siglip_so400m(default_image_size, **tk.get("siglip", {}))
         if "sam" in towers:
             self.sam_featurizer = SamImageEncoder(**tk.get("sam", {}))
+        if vision_tower_path:           # the reference's pretrained files: all requested towers must load, or it is an error
+            for name, loader in (("dino", load_timm_vit), ("siglip", load_timm_vit), ("sam", load_sam_encoder)):
+                if name in towers:
+                    if name not in vision_tower_path:
+                        raise KeyError(f"vision_tower_path has no entry for the '{name}' tower")
+                    loader(getattr(self, f"{name}_featurizer"), vision_tower_path[name])
         self.eval()
 
     @property
