@@ -126,9 +126,9 @@ def cpu_baseline(n_embd, T):
               "bwd_GBps": elems * BWD_B / kb / 1e9, "tokens_per_s_per_layer": T / (kf + kb)}
     # the reference's own pure-PyTorch statement of the recurrence (VisualRWKV-v6/v6.xx/RWKV-v7_simple.py:20-32, restated in
     # oracle.wkv7_oracle.wkv7_naive): per-token matmuls over (B,H,64,64), fp32, forward + autograd backward, same shape
-    # (bounded sample: the first 512 tokens -- the per-token cost does not depend on T; the full 2624 tokens take ~40 s a run)
+    # (bounded sample: the first 128 tokens -- the per-token cost does not depend on T; 512 tokens took 9.4 s a run on the 128-core host)
     from oracle.wkv7_oracle import wkv7_naive
-    Tp = min(T, 512)
+    Tp = min(T, 128)
     pt = []
     for it in range(6):
         leaves = [x[:, :Tp].float().requires_grad_(True) for x in (ow, oq, ok_, ov, oz, oa)]

@@ -230,6 +230,23 @@ int vrwkv_adamw_step_bf16(long n, float* master, float* m, float* v, const void*
                           float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                           float grad_scale, long global_offset, long wd_boundary, void* stream);
 
+/* ---- image side: pooling, context gate, LayerNorm + scatter (src/model.py:328-338,442-447,485-493) ------------------ */
+/* nn.AdaptiveAvgPool2d(side_out) of a token-major ViT feature map: x (B, side_in^2, D) -> y (B, side_out^2, D) bf16,
+ * PyTorch's window rule (also side_out > side_in), fp32 accumulation.  D % 8 == 0. */
+int vrwkv_adaptive_pool_bf16(int B, int side_in, int side_out, int D, const void* x, void* y, void* stream);
+/* MLPWithContextGating's gate: out = x * sigmoid(g) over n bf16 elements (n % 8 == 0); backward dg = dout x s (1 - s)
+ * and, when dx is not NULL, dx = dout s. */
+int vrwkv_gate_fwd_bf16(long n, const void* x, const void* g, void* out, void* stream);
+int vrwkv_gate_bwd_bf16(long n, const void* x, const void* g, const void* dout, void* dg, void* dx, void* stream);
+/* ln_v of the projector fused with the masked scatter of preparing_embedding: out[row_index[n]] = LayerNorm(x[n]) for the
+ * ntok projected image tokens, written into the (rows, C) token-embedding tensor `out`; row_index: device int64.  mean /
+ * rstd (ntok fp32 each) are saved for the backward, which reads dout[row_index[n]] and returns dx (ntok, C) and
+ * dwb = (dgamma, dbeta) (2 C fp32); ws: vrwkv_add_ln_ws_floats(ntok, C) floats. */
+int vrwkv_ln_scatter_fwd_bf16(long ntok, int C, float eps, const void* x, const void* w, const void* b, const long* row_index,
+                              void* out, float* mean, float* rstd, void* stream);
+int vrwkv_ln_gather_bwd_bf16(long ntok, int C, const void* dout, const long* row_index, const void* x, const float* mean,
+                             const float* rstd, const void* w, void* dx, float* dwb, float* ws, void* stream);
+
 /* The same step with the clip factor formed on the device: sqnorm[0] = squared L2 norm of the (unscaled, summed over
  * ranks) gradient, grad scale = inv_world * min(1, clip / (sqrt(sqnorm) * inv_world + 1e-6)) (clip <= 0: no clipping).
  * Replaces Lightning's gradient_clip_val=1.0 host-side norm (train.py:92) without a device -> host synchronisation. */

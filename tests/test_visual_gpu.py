@@ -49,6 +49,46 @@ def test_adaptive_pooling_and_scatter_gpu(gold):
     assert torch.equal(y.cpu(), s["y"])          # indexing is bit-exact
 
 
+def test_fused_projector_pool_scatter_match_eager_and_fixture(gold):
+    """The HIP kernels of the image side (adaptive pool, context gate, ln_v + scatter) inside VisualRWKV.preparing_embedding
+    against (a) the eager torch statement of the same modules on the GPU, forward and parameter gradients, and (b) the
+    reference fixtures for the pool (model.py:442-447)."""
+    from visualrwkv_amd import fused
+    from visualrwkv_amd.visual import MLPWithContextGating
+    g = gold["pool"]
+    x = g["x"].cuda().bfloat16()
+    y = fused.adaptive_pool(x, g["out_side"])
+    assert rel_rms(y.float().cpu(), g["y"]) < 5e-3
+    up = fused.adaptive_pool(x[:, :16], 6)                      # 4x4 grid -> 6x6: the up-sampling windows of cfg 5
+    ref_up = nn.AdaptiveAvgPool2d(6)(x[:, :16].float().view(x.shape[0], 4, 4, -1).permute(0, 3, 1, 2)).flatten(2).permute(0, 2, 1)
+    assert rel_rms(up.float(), ref_up) < 5e-3
+
+    torch.manual_seed(0)
+    D, C, n_img, T = 192, 128, 40, 64
+    proj = MLPWithContextGating(D, C).cuda().bfloat16()
+    with torch.no_grad():
+        proj.ln_v.weight.normal_(1, 0.2); proj.ln_v.bias.normal_(0, 0.2)
+    feats = torch.randn(n_img, D, device="cuda").bfloat16()
+    emb = torch.randn(2 * T, C, device="cuda").bfloat16()
+    sel = torch.zeros(2 * T, dtype=torch.bool, device="cuda")
+    sel[3:23] = True; sel[T + 10:T + 30] = True
+    gout = torch.randn(2 * T, C, device="cuda").bfloat16()
+    # eager statement
+    eager = proj.ln_v(proj.o_proj(feats * torch.sigmoid(proj.gate(feats))))     # src/model.py:328-338, spelled in torch
+    ref = emb.clone().masked_scatter(sel[:, None], eager)
+    ref.backward(gout)
+    gref = {n: p.grad.clone() for n, p in proj.named_parameters()}
+    proj.zero_grad()
+    # fused path
+    rows = torch.argsort(~sel, stable=True)[:n_img]
+    out = fused.ln_scatter(emb.clone(), proj.pre_norm(feats), proj.ln_v, rows)
+    out.backward(gout)
+    assert torch.equal(out[~sel], ref[~sel])                     # untouched rows: bit-exact
+    assert rel_rms(out[sel].float(), ref[sel].float()) < 1e-2
+    for n, p in proj.named_parameters():
+        assert rel_rms(p.grad.float(), gref[n].float()) < 2e-2, n
+
+
 def test_sam_encoder_gpu(gold):
     """Scaled SAM configuration of the fixture (128^2 input, window 3, one global block) through the product path."""
     from visualrwkv_amd.vit import SamImageEncoder

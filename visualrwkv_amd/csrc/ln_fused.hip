@@ -56,7 +56,8 @@ DEVFN void block_sum(float (*red)[MAXW][2], int slot, int wave, int lane, int nw
 __global__ __launch_bounds__(1024) void add_ln_fwd_kernel(long ntok, int C, float eps, const uint16_t* __restrict__ x,
                                                           const uint16_t* __restrict__ delta, const uint16_t* __restrict__ w,
                                                           const uint16_t* __restrict__ b, uint16_t* __restrict__ xn,
-                                                          uint16_t* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd) {
+                                                          uint16_t* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                          const long* __restrict__ yrow) {
     __shared__ float red[4][MAXW][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int c0 = threadIdx.x * 8;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(1024) void add_ln_fwd_kernel(long ntok, int C, floa
         V8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o.f[e] = fmaf((v.f[e] - mu) * rs, wv.f[e], bv.f[e]);
-        if (act) *reinterpret_cast<uint4*>(y + n * C + c0) = pack8(o);
+        if (act) *reinterpret_cast<uint4*>(y + (yrow ? yrow[n] : n) * C + c0) = pack8(o);      // yrow: scatter into a larger tensor
         if (threadIdx.x == 0) { mean[n] = mu; rstd[n] = rs; }
     }
 }
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(1024) void add_ln_bwd_kernel(long ntok, int C, cons
                                                           const uint16_t* __restrict__ dres, const uint16_t* __restrict__ xn,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const uint16_t* __restrict__ w, uint16_t* __restrict__ dx,
-                                                          float* __restrict__ part) {
+                                                          float* __restrict__ part, const long* __restrict__ yrow) {
     __shared__ float red[2][MAXW][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int c0 = threadIdx.x * 8;
@@ -120,14 +121,14 @@ __global__ __launch_bounds__(1024) void add_ln_bwd_kernel(long ntok, int C, cons
     uint4 ny = z4, nx = z4, nr = z4;
     float nmu = 0.f, nrs = 0.f;
     if (lo < hi) {
-        if (act) { ny = ldg(dy + lo * C + c0); nx = ldg(xn + lo * C + c0); if (dres) nr = ldg(dres + lo * C + c0); }
+        if (act) { ny = ldg(dy + (yrow ? yrow[lo] : lo) * C + c0); nx = ldg(xn + lo * C + c0); if (dres) nr = ldg(dres + lo * C + c0); }
         nmu = mean[lo]; nrs = rstd[lo];
     }
     for (long n = lo; n < hi; ++n) {
         const uint4 cy = ny, cx = nx, cr = nr;
         const float mu = nmu, rs = nrs;
         if (n + 1 < hi) {
-            if (act) { ny = ldg(dy + (n + 1) * C + c0); nx = ldg(xn + (n + 1) * C + c0); if (dres) nr = ldg(dres + (n + 1) * C + c0); }
+            if (act) { ny = ldg(dy + (yrow ? yrow[n + 1] : n + 1) * C + c0); nx = ldg(xn + (n + 1) * C + c0); if (dres) nr = ldg(dres + (n + 1) * C + c0); }
             nmu = mean[n + 1]; nrs = rstd[n + 1];
         }
         const V8 d = unpack8(cy), xv = unpack8(cx);
@@ -195,7 +196,34 @@ int vrwkv_add_ln_fwd_bf16(long ntok, int C, float eps, const void* x, const void
     if (!ln_ok(C)) return VRWKV_ESHAPE;
     hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(ln_grid(ntok)), dim3(ln_threads(C)), 0, (hipStream_t)stream, ntok, C, eps,
                        (const uint16_t*)x, (const uint16_t*)delta, (const uint16_t*)w, (const uint16_t*)b, (uint16_t*)xn,
-                       (uint16_t*)y, mean, rstd);
+                       (uint16_t*)y, mean, rstd, (const long*)nullptr);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? VRWKV_OK : (int)e;
+}
+
+// LayerNorm of the projector output written straight into the rows of the token-embedding tensor that hold the image
+// placeholders (MLPWithContextGating's ln_v + the masked scatter of preparing_embedding, src/model.py:338,485-493):
+// out[row_index[n]] = LN(x[n]).  row_index: device int64, strictly increasing.
+int vrwkv_ln_scatter_fwd_bf16(long ntok, int C, float eps, const void* x, const void* w, const void* b, const long* row_index,
+                              void* out, float* mean, float* rstd, void* stream) {
+    if (ntok <= 0 || !x || !w || !b || !row_index || !out || !mean || !rstd) return VRWKV_EINVAL;
+    if (!ln_ok(C)) return VRWKV_ESHAPE;
+    hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(ln_grid(ntok)), dim3(ln_threads(C)), 0, (hipStream_t)stream, ntok, C, eps,
+                       (const uint16_t*)x, (const uint16_t*)nullptr, (const uint16_t*)w, (const uint16_t*)b, (uint16_t*)nullptr,
+                       (uint16_t*)out, mean, rstd, row_index);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? VRWKV_OK : (int)e;
+}
+
+// ... and its backward: dx[n] = LN'(dout[row_index[n]]), dwb = (dgamma, dbeta); ws as for vrwkv_add_ln_bwd_bf16
+int vrwkv_ln_gather_bwd_bf16(long ntok, int C, const void* dout, const long* row_index, const void* x, const float* mean,
+                             const float* rstd, const void* w, void* dx, float* dwb, float* ws, void* stream) {
+    if (ntok <= 0 || !dout || !row_index || !x || !mean || !rstd || !w || !dx || !dwb || !ws) return VRWKV_EINVAL;
+    if (!ln_ok(C)) return VRWKV_ESHAPE;
+    const int G = ln_grid(ntok);
+    hipLaunchKernelGGL(add_ln_bwd_kernel, dim3(G), dim3(ln_threads(C)), 0, (hipStream_t)stream, ntok, C, (const uint16_t*)dout,
+                       (const uint16_t*)nullptr, (const uint16_t*)x, mean, rstd, (const uint16_t*)w, (uint16_t*)dx, ws, row_index);
+    hipLaunchKernelGGL(ln_colsum_kernel, dim3((unsigned)(2L * C / 64)), dim3(256), 0, (hipStream_t)stream, G, 2L * C, ws, dwb);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? VRWKV_OK : (int)e;
 }
@@ -206,7 +234,7 @@ int vrwkv_add_ln_bwd_bf16(long ntok, int C, const void* dy, const void* dres, co
     if (!ln_ok(C)) return VRWKV_ESHAPE;
     const int G = ln_grid(ntok);
     hipLaunchKernelGGL(add_ln_bwd_kernel, dim3(G), dim3(ln_threads(C)), 0, (hipStream_t)stream, ntok, C, (const uint16_t*)dy,
-                       (const uint16_t*)dres, (const uint16_t*)xn, mean, rstd, (const uint16_t*)w, (uint16_t*)dx, ws);
+                       (const uint16_t*)dres, (const uint16_t*)xn, mean, rstd, (const uint16_t*)w, (uint16_t*)dx, ws, (const long*)nullptr);
     hipLaunchKernelGGL(ln_colsum_kernel, dim3((unsigned)(2L * C / 64)), dim3(256), 0, (hipStream_t)stream, G, 2L * C, ws, dwb);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? VRWKV_OK : (int)e;

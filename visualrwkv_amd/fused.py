@@ -505,3 +505,92 @@ def cmix_forward(m, x):
     """RWKV_CMix_x070.forward (src/model.py:221-227)."""
     (k,) = mix(x, m.x_k)
     return m.value(relu_sq(m.key(k)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Image side (csrc/visual_ops.hip, vrwkv_ln_scatter_* in csrc/ln_fused.hip): pooling, context gate, ln_v + scatter
+# (VisualRWKV-v7/v7.00/src/model.py:328-338,442-447,485-493)
+# ---------------------------------------------------------------------------------------------------------------
+def visual_supported(x):
+    return x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 8 == 0
+
+
+def adaptive_pool(image_features, side_out):
+    """nn.AdaptiveAvgPool2d(side_out) on token-major ViT features (B, L, D) -> (B, side_out^2, D) without the
+    (B, D, H, W) permutes of VisualRWKV.adaptive_pooling; forward only (the towers are frozen and detached)."""
+    x = image_features.detach().contiguous()
+    _chk(x)
+    B, Ln, D = x.shape
+    side = int(round(Ln ** 0.5))
+    if side * side != Ln:
+        raise ValueError(f"{Ln} patch tokens are not a square grid")
+    y = torch.empty(B, side_out * side_out, D, dtype=x.dtype, device=x.device)
+    hip_lib.check(hip_lib.load().vrwkv_adaptive_pool_bf16(B, side, side_out, D, x.data_ptr(), y.data_ptr(), _stream(x)),
+                  "vrwkv_adaptive_pool_bf16")
+    return y
+
+
+class _Gate(torch.autograd.Function):
+    """x * sigmoid(g) in one pass (model.py:337); backward dg (and dx when x needs it) in one pass."""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        x, g = x.contiguous(), g.contiguous()
+        _chk(x, g)
+        out = torch.empty_like(x)
+        hip_lib.check(hip_lib.load().vrwkv_gate_fwd_bf16(x.numel(), x.data_ptr(), g.data_ptr(), out.data_ptr(), _stream(x)), "vrwkv_gate_fwd_bf16")
+        ctx.save_for_backward(x, g)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, g = ctx.saved_tensors
+        dout = dout.contiguous()
+        dg = torch.empty_like(g)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        hip_lib.check(hip_lib.load().vrwkv_gate_bwd_bf16(x.numel(), x.data_ptr(), g.data_ptr(), dout.data_ptr(), dg.data_ptr(), _p(dx), _stream(x)),
+                      "vrwkv_gate_bwd_bf16")
+        return dx, dg
+
+
+def gate(x, g):
+    return _Gate.apply(x, g)
+
+
+class _LnScatter(torch.autograd.Function):
+    """embeds[row_index[n]] = LayerNorm(y[n]): ln_v of the projector fused with the masked scatter into the token
+    embeddings (model.py:338 + :485-493).  `embeds` (rows, C) is modified in place and returned."""
+
+    @staticmethod
+    def forward(ctx, embeds, y, w, b, row_index, eps):
+        y = y.contiguous()
+        _chk(embeds, y, w, b)
+        n, C = y.shape
+        mean = torch.empty(n, dtype=torch.float32, device=y.device)
+        rstd = torch.empty_like(mean)
+        hip_lib.check(hip_lib.load().vrwkv_ln_scatter_fwd_bf16(n, C, float(eps), y.data_ptr(), w.data_ptr(), b.data_ptr(), row_index.data_ptr(),
+                                                               embeds.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _stream(y)), "vrwkv_ln_scatter_fwd_bf16")
+        ctx.mark_dirty(embeds)
+        ctx.save_for_backward(y, w, mean, rstd, row_index)
+        return embeds
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, w, mean, rstd, row_index = ctx.saved_tensors
+        dout = dout.contiguous()
+        n, C = y.shape
+        lib = hip_lib.load()
+        dy = torch.empty_like(y)
+        dwb = torch.empty(2, C, dtype=torch.float32, device=y.device)
+        ws = torch.empty(lib.vrwkv_add_ln_ws_floats(n, C), dtype=torch.float32, device=y.device)
+        hip_lib.check(lib.vrwkv_ln_gather_bwd_bf16(n, C, dout.data_ptr(), row_index.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                   w.data_ptr(), dy.data_ptr(), dwb.data_ptr(), ws.data_ptr(), _stream(y)), "vrwkv_ln_gather_bwd_bf16")
+        d_emb = None
+        if ctx.needs_input_grad[0]:                    # rows that were overwritten do not reach the embedding
+            d_emb = dout.clone()
+            d_emb.index_fill_(0, row_index, 0)
+        return d_emb, dy, dwb[0].to(w.dtype), dwb[1].to(w.dtype), None, None
+
+
+def ln_scatter(embeds2d, y2d, ln, row_index):
+    return _LnScatter.apply(embeds2d, y2d, ln.weight, ln.bias, row_index, ln.eps)

@@ -52,6 +52,11 @@ PROTOTYPES = {
     "vrwkv_relusq_bwd_bf16": (_c_int, [ctypes.c_long] + [_c_void_p] * 4),
     "vrwkv_attention_fwd_bf16": (_c_int, [_c_int] * 4 + [_c_void_p] * 3 + [ctypes.c_long] * 3 + [_c_void_p] * 2),
     "vrwkv_adamw_step_bf16": (_c_int, [ctypes.c_long] + [_c_void_p] * 5 + [ctypes.c_float] * 5 + [_c_int, ctypes.c_float, ctypes.c_long, ctypes.c_long, _c_void_p]),
+    "vrwkv_adaptive_pool_bf16": (_c_int, [_c_int] * 4 + [_c_void_p] * 3),
+    "vrwkv_gate_fwd_bf16": (_c_int, [_c_long] + [_c_void_p] * 4),
+    "vrwkv_gate_bwd_bf16": (_c_int, [_c_long] + [_c_void_p] * 6),
+    "vrwkv_ln_scatter_fwd_bf16": (_c_int, [_c_long, _c_int, _c_float] + [_c_void_p] * 8),
+    "vrwkv_ln_gather_bwd_bf16": (_c_int, [_c_long, _c_int] + [_c_void_p] * 10),
     "vrwkv_adamw_step_clip_bf16": (_c_int, [ctypes.c_long] + [_c_void_p] * 5 + [ctypes.c_float] * 5 + [_c_int, _c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_long, ctypes.c_long, _c_void_p]),
     "vrwkv_sqnorm_bf16": (_c_int, [ctypes.c_long, _c_void_p, _c_void_p, _c_void_p]),
     "vrwkv_wkv7_profile_bf16": (_c_int, [_c_int] * 4 + [_c_void_p] * 18),

@@ -27,7 +27,15 @@ class MLPWithContextGating(nn.Module):
         self.ln_v = nn.LayerNorm(n_embd)
 
     def forward(self, x):
-        return self.ln_v(self.o_proj(x * torch.sigmoid(self.gate(x))))
+        return self.ln_v(self.pre_norm(x))
+
+    def pre_norm(self, x):
+        """o_proj(x * sigmoid(gate(x))): everything before ln_v.  On the GPU the gate is one streaming HIP kernel and
+        ln_v is fused with the scatter into the token embeddings by the caller (VisualRWKV.preparing_embedding)."""
+        from . import fused
+        if fused.visual_supported(x) and self.gate.weight.dtype == torch.bfloat16:
+            return self.o_proj(fused.gate(x, self.gate(x)))
+        return self.o_proj(x * torch.sigmoid(self.gate(x)))
 
 
 class VisualRWKV(nn.Module):
@@ -78,12 +86,16 @@ class VisualRWKV(nn.Module):
 
     # ---- forward path
     def adaptive_pooling(self, image_features):
+        from . import fused
+        if getattr(getattr(self, "args", None), "fused", False) and fused.visual_supported(image_features):
+            osz = self.pool.output_size
+            return fused.adaptive_pool(image_features, osz if isinstance(osz, int) else osz[0])
         B, Ln, D = image_features.shape
         side = int(Ln ** 0.5)
         x = image_features.view(B, side, side, D).permute(0, 3, 1, 2)
         return self.pool(x).view(B, D, -1).permute(0, 2, 1)
 
-    def encode_images(self, images: dict, minibatch_size: int = 4) -> torch.Tensor:
+    def encode_images(self, images: dict, minibatch_size: int = 4, normed: bool = True) -> torch.Tensor:
         """ViTs (frozen, no grad) in mini-batches of `minibatch_size` images -> pool -> projector
         (src/model.py:449-471; the reference's per-mini-batch torch.cuda.empty_cache() is a device sync
         plus an allocator flush and is deliberately not reproduced)."""
@@ -94,17 +106,30 @@ class VisualRWKV(nn.Module):
             for i in range(0, n, minibatch_size):
                 feats.append(self.vit({k: images[k][i:i + minibatch_size] for k in keys}))
         image_features = feats[0] if len(feats) == 1 else torch.cat(feats, dim=0)
-        return self.proj(self.adaptive_pooling(image_features.detach()))
+        pooled = self.adaptive_pooling(image_features.detach())
+        if normed:
+            return self.proj(pooled)
+        return self.proj.pre_norm(pooled)               # ln_v is applied by the fused scatter
 
     def preparing_embedding(self, samples):
         if "images" not in samples:
             return self.rwkv.emb(samples["input_ids"]), samples["labels"]
-        image_features = self.encode_images(samples["images"])
-        image_features = image_features.view(-1, image_features.shape[-1])
         input_embeds = self.rwkv.emb(samples["input_ids"])
         B, Ln, D = input_embeds.shape
         input_embeds = input_embeds.view(B * Ln, D)
         selected = samples["input_ids"].view(B * Ln) == IMAGE_TOKEN_INDEX
+        from . import fused
+        if (getattr(self.args, "fused", False) and isinstance(getattr(self, "proj", None), MLPWithContextGating) and fused.visual_supported(input_embeds)
+                and not getattr(self.args, "check_image_tokens", True) and self.proj.ln_v.weight.dtype == torch.bfloat16 and D % 64 == 0):
+            # GPU path: ln_v of the projector writes straight into the placeholder rows (no masked_scatter, no host sync:
+            # the row list comes from a stable sort of the mask; the caller vouches for the token count, as the bench does)
+            feats = self.encode_images(samples["images"], normed=False)
+            feats = feats.reshape(-1, feats.shape[-1])
+            rows = torch.argsort(~selected, stable=True)[:feats.shape[0]]
+            input_embeds = fused.ln_scatter(input_embeds, feats, self.proj.ln_v, rows)
+            return input_embeds.view(B, Ln, D), samples["labels"]
+        image_features = self.encode_images(samples["images"])
+        image_features = image_features.view(-1, image_features.shape[-1])
         n_sel = int(selected.sum()) if getattr(self.args, "check_image_tokens", True) else image_features.shape[0]
         if n_sel != image_features.shape[0]:
             n_feat = image_features.shape[0]
