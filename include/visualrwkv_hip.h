@@ -221,6 +221,27 @@ int vrwkv_relusq_bwd_bf16(long n, const void* h, const void* dy, void* dh, void*
 int vrwkv_attention_fwd_bf16(int B, int L, int H, int D, const void* q, const void* k, const void* v,
                              long stride_b, long stride_l, long stride_h, void* o, void* stream);
 
+/* The same with SAM's decomposed relative-position bias added to the logits inside the kernel (replaces
+ * Attention.forward + add_decomposed_rel_pos, VisualRWKV-v7/v7.00/src/sam.py:289-305, 392-426, without the
+ * (B, H, L, L) bias tensor): L = S*S tokens of an S x S window (S = 14: windowed blocks, S = 64: global blocks),
+ * logit(q, k) = q.k / sqrt(D) + q.rel_h[qh - kh + S - 1] + q.rel_w[qw - kw + S - 1] with the UNSCALED q.
+ * rel_h / rel_w: (2S-1, D) bf16 contiguous (already interpolated to 2S-1 rows, sam.py:371-381).  D = 64. */
+int vrwkv_attention_relpos_fwd_bf16(int B, int S, int H, int D, const void* q, const void* k, const void* v,
+                                    long stride_b, long stride_l, long stride_h, const void* rel_h, const void* rel_w,
+                                    void* o, void* stream);
+/* Patch embedding of the ViT towers as an implicit GEMM over the NCHW pixels, bias and position embedding fused
+ * (replaces timm PatchEmbed + pos_embed add run via VisualRWKV-v7/v7.00/src/vision.py:123-134 and
+ * PatchEmbed.forward + pos_embed of src/sam.py:118-121,468-483):
+ *   out[b, prefix + m, n] = sum_{c,py,px} pixels[b, c, gy P + py, gx P + px] w[n, (c P + py) P + px] + bias[n] + pos[m, n]
+ * pixels (B,3,Himg,Wimg) bf16; w_padded (N, KP) bf16 = the conv weight flattened to (N, 3 P P) and zero-padded to
+ * KP = vrwkv_patch_embed_kp(P) columns; bias (N) / pos (M, N) bf16 or NULL; out (B, tokens_per_image, N) bf16, rows
+ * < prefix of each image are left untouched (class / register tokens).  P in {14, 16}; (Himg/P)(Wimg/P) % 64 == 0. */
+int vrwkv_patch_embed_bf16(int B, int Himg, int Wimg, int P, int N, const void* pixels, const void* w_padded,
+                           const void* bias, const void* pos, void* out, int tokens_per_image, int prefix, void* stream);
+int vrwkv_patch_embed_kp(int P);
+/* Test hook: query tiles of 16 per wave in the attention kernels (1 or 2; 0 = default = 2). */
+int vrwkv_attention_set_qtiles(int qt);
+
 /* Fused AdamW step on a flat ZeRO-1 shard (replaces DeepSpeed's FusedAdam(adam_w_mode=True) that the
  * reference configures in VisualRWKV-v7/v7.00/src/model.py:410): fp32 master/m/v, bf16 gradient in, bf16
  * parameter out, gradient pre-scaled by grad_scale (clip coefficient / world size), bias correction for

@@ -47,6 +47,17 @@ DEVFN uint32_t emu_wave_read(uint32_t x, int src) {
     emu::wave_barrier();
     return r;
 }
+DEVFN float max3_f32(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+DEVFN f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { f32x2 r = {fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; return r; }
+DEVFN bool wave_any(bool x) {
+    emu::slot(emu::flat_tid())[0] = x ? 1u : 0u;
+    emu::wave_barrier();
+    bool r = false;
+    for (int l = 0; l < 64; ++l) r = r || emu::slot(emu::wave_base() + l)[0] != 0;
+    emu::wave_barrier();
+    return r;
+}
 DEVFN float lane_xor(float x, int mask) { return __uint_as_float(emu_wave_read(__float_as_uint(x), lane_id() ^ mask)); }
 DEVFN float lane_xor16(float x) { return lane_xor(x, 16); }
 DEVFN float lane_xor32(float x) { return lane_xor(x, 32); }

@@ -72,16 +72,59 @@ def test_backward_chunked(emu_lib, mode):
         assert rel_rms(o.float(), r.float()) < 1e-3, (name, mode)
 
 
-@pytest.mark.parametrize("D,L", [(64, 70), (72, 48)])
-def test_attention_forward(emu_lib, D, L):
-    """ViT attention kernel (csrc/attention_kernels.h) vs fp32 softmax attention; q/k/v are strided slices of one
-    fused qkv tensor as in the towers; L is not a multiple of the key tile (tail masking)."""
-    B, H = 1, 2
-    g = torch.Generator().manual_seed(D)
+def _sam_bias(q, rel_h, rel_w, S):
+    """add_decomposed_rel_pos (src/sam.py:392-426) in fp32: (B, H, L, L) bias from the unscaled q."""
+    B, L, H, D = q.shape
+    idx = torch.arange(S)
+    Rh = rel_h.float()[(idx[:, None] - idx[None, :]) + (S - 1)]
+    Rw = rel_w.float()[(idx[:, None] - idx[None, :]) + (S - 1)]
+    rq = q.float().reshape(B, S, S, H, D)
+    bh = torch.einsum("bhwnc,hkc->bnhwk", rq, Rh)
+    bw = torch.einsum("bhwnc,wkc->bnhwk", rq, Rw)
+    return (bh[..., :, None] + bw[..., None, :]).reshape(B, H, L, L)
+
+
+@pytest.mark.parametrize("D,L,qt,S", [(64, 70, 1, 0), (64, 200, 2, 0), (72, 48, 1, 0), (72, 150, 2, 0), (64, 196, 1, 14),
+                                      (64, 196, 2, 14), (64, 4096, 2, 64)])
+def test_attention_forward(emu_lib, D, L, qt, S):
+    """ViT attention kernels (csrc/attention_kernels.h) vs fp32 softmax attention; q/k/v are strided slices of one
+    fused qkv tensor as in the towers; L is not a multiple of the key tile (tail masking); S > 0: SAM window with the
+    decomposed relative-position bias computed inside the kernel."""
+    B, H = 1, (1 if S == 64 else 2)
+    g = torch.Generator().manual_seed(D + L)
     qkv = (torch.randn(B, L, 3, H, D, generator=g)).bfloat16()
     q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
     o = torch.zeros(B, L, H, D, dtype=torch.bfloat16)
     sb, sl, sh, _ = q.stride()
-    emu_lib.emu_attention_fwd(B, L, H, D, P(q), P(k), P(v), ctypes.c_long(sb), ctypes.c_long(sl), ctypes.c_long(sh), P(o))
-    ref = torch.nn.functional.scaled_dot_product_attention(q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2)).transpose(1, 2)
+    bias, rh, rw = None, None, None
+    if S:
+        rh = (0.3 * torch.randn(2 * S - 1, D, generator=g)).bfloat16()
+        rw = (0.3 * torch.randn(2 * S - 1, D, generator=g)).bfloat16()
+        bias = _sam_bias(q, rh, rw, S)
+    rc = emu_lib.emu_attention_fwd(B, L, H, D, P(q), P(k), P(v), ctypes.c_long(sb), ctypes.c_long(sl), ctypes.c_long(sh), P(o),
+                                   qt, S, P(rh) if S else None, P(rw) if S else None)
+    assert rc == 0
+    ref = torch.nn.functional.scaled_dot_product_attention(q.float().transpose(1, 2), k.float().transpose(1, 2),
+                                                           v.float().transpose(1, 2), attn_mask=bias).transpose(1, 2)
     assert rel_rms(o.float(), ref) < 1e-2
+
+
+@pytest.mark.parametrize("patch,side,N,prefix", [(14, 112, 32, 5), (16, 128, 48, 0)])
+def test_patch_embed(emu_lib, patch, side, N, prefix):
+    """Implicit-GEMM patch embedding (csrc/patch_embed_kernels.h) vs conv2d + bias + position embedding in fp32."""
+    B = 2
+    g = torch.Generator().manual_seed(patch)
+    x = torch.randn(B, 3, side, side, generator=g).bfloat16()
+    w = (0.05 * torch.randn(N, 3, patch, patch, generator=g)).bfloat16()
+    bias = (0.1 * torch.randn(N, generator=g)).bfloat16()
+    M = (side // patch) ** 2
+    pos = (0.1 * torch.randn(M, N, generator=g)).bfloat16()
+    K, KP = 3 * patch * patch, (3 * patch * patch + 31) // 32 * 32
+    wp = torch.zeros(N, KP, dtype=torch.bfloat16)
+    wp[:, :K] = w.reshape(N, K)
+    out = torch.full((B, prefix + M, N), 7.0, dtype=torch.bfloat16)
+    rc = emu_lib.emu_patch_embed(B, side, side, patch, N, P(x), P(wp), P(bias), P(pos), P(out), prefix + M, prefix)
+    assert rc == 0
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), bias.float(), stride=patch).flatten(2).transpose(1, 2) + pos.float()
+    assert rel_rms(out[:, prefix:].float(), ref) < 5e-3
+    assert torch.all(out[:, :prefix] == 7.0)             # prefix rows untouched

@@ -222,3 +222,18 @@ def test_vision_tower_checkpoints_load_or_fail_loudly(tmp_path):
         SamDinoSigLIPViTBackbone({**paths, "dino": paths["siglip"]}, default_image_size=56, tower_kwargs=kw)
     with pytest.raises(KeyError):
         SamDinoSigLIPViTBackbone({"dino": paths["dino"]}, default_image_size=56, tower_kwargs=kw)
+
+
+@pytest.mark.parametrize("case", ["win14", "glob64"])
+def test_sam_attention_restatement_against_reference_fixture(case):
+    """The torch statement of SAM's attention + decomposed rel-pos bias (vit._SamAttention, attention.attention_relpos)
+    against outputs of the reference's own module at the real window sizes (tests/golden/make_golden_sam_attn.py)."""
+    import os
+    from visualrwkv_amd.vit import _SamAttention
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "sam_attn_ref.pt"), weights_only=True)[case]
+    m = _SamAttention(g["dim"], g["heads"], (g["side"], g["side"]))
+    m.load_state_dict({k: v.float() for k, v in g["state"].items()}, strict=True)
+    with torch.no_grad():
+        y = m(g["x"].float())
+    tol = 2e-3 if case == "glob64" else 1e-5              # glob64 output is stored as fp16
+    assert rel_rms(y, g["y"].float()) < tol

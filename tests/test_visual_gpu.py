@@ -103,3 +103,50 @@ def test_sam_encoder_gpu(gold):
         neck = m.neck(h.permute(0, 3, 1, 2))
     assert rel_rms(h.float().cpu(), g["tokens"]) < 2 * TOL
     assert rel_rms(neck.float().cpu(), g["neck"]) < 3 * TOL
+
+
+@pytest.mark.parametrize("patch,side,N,npre", [(14, 448, 1152, 0), (14, 448, 1024, 5), (16, 256, 768, 0), (16, 1024, 768, 0)])
+def test_patch_embed_kernel_against_conv2d(patch, side, N, npre):
+    """Implicit-GEMM patch embedding (bias + position embedding fused, prefix tokens in place) vs fp32 conv2d on the same
+    bf16 pixels / weights, at the tower shapes (SigLIP 1152, DINOv2 1024 + 5 prefix tokens, SAM 768 at 1024^2)."""
+    from visualrwkv_amd import fused
+    B = 2
+    g = torch.Generator().manual_seed(patch + N)
+    x = torch.randn(B, 3, side, side, generator=g).bfloat16().cuda()
+    w = (0.03 * torch.randn(N, 3, patch, patch, generator=g)).bfloat16().cuda()
+    bias = (0.1 * torch.randn(N, generator=g)).bfloat16().cuda()
+    M = (side // patch) ** 2
+    pos = (0.1 * torch.randn(M, N, generator=g)).bfloat16().cuda()
+    pre = torch.randn(npre, N, generator=g).bfloat16().cuda() if npre else None
+    assert fused.patch_embed_supported(x, patch, N)
+    out = fused.patch_embed(x, w, bias, pos, pre)
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), bias.float(), stride=patch).flatten(2).transpose(1, 2) + pos.float()
+    assert out.shape == (B, npre + M, N)
+    assert rel_rms(out[:, npre:].float(), ref) < 5e-3
+    if npre:
+        assert torch.equal(out[:, :npre], pre.expand(B, -1, -1))
+
+
+def test_towers_use_the_patch_embed_kernel(monkeypatch):
+    """TimmViT / SamImageEncoder route bf16 GPU inputs through the kernel and agree with their eager statement."""
+    from visualrwkv_amd import fused
+    from visualrwkv_amd.vit import TimmViT, SamImageEncoder
+    torch.manual_seed(0)
+    calls = []
+    orig = fused.patch_embed
+    monkeypatch.setattr(fused, "patch_embed", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    vit = TimmViT(img_size=224, patch=14, dim=128, depth=2, heads=2, mlp_hidden=256, class_token=True, reg_tokens=4, ls_init=0.5).bfloat16().cuda()
+    sam = SamImageEncoder(img_size=256, patch=16, dim=128, depth=2, heads=2, out_chans=16, window=4, global_attn_indexes=(1,)).bfloat16().cuda()
+    for m in (vit, sam):
+        for p_ in m.parameters():
+            p_.requires_grad_(False)
+    xv = torch.randn(2, 3, 224, 224, device="cuda").bfloat16()
+    xs = torch.randn(2, 3, 256, 256, device="cuda").bfloat16()
+    with torch.no_grad():
+        a_v, a_s = vit(xv), sam(xs)
+        assert len(calls) == 2
+        monkeypatch.setattr(fused, "patch_embed_supported", lambda *a, **k: False)
+        b_v, b_s = vit(xv), sam(xs)
+    assert len(calls) == 2
+    assert rel_rms(a_v.float(), b_v.float()) < 1e-2
+    assert rel_rms(a_s.float(), b_s.float()) < 1e-2

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libvisualrwkv_hip.so")
 HASH_PATH = LIB_PATH + ".hash"      # content hash of the sources the library was built from; travels with it
 ARCH = "gfx950"
 
-SOURCES = ["wkv7_capi.hip", "probe.hip", "fused_ops.hip", "tmix_fused.hip", "attention.hip", "wkv7_step.hip", "ln_fused.hip", "wkv6_capi.hip", "loss_fused.hip", "gemv_decode.hip", "decode_fused.hip", "lora_wgrad.hip", "visual_ops.hip"]
+SOURCES = ["wkv7_capi.hip", "probe.hip", "fused_ops.hip", "tmix_fused.hip", "attention.hip", "wkv7_step.hip", "ln_fused.hip", "wkv6_capi.hip", "loss_fused.hip", "gemv_decode.hip", "decode_fused.hip", "lora_wgrad.hip", "visual_ops.hip", "patch_embed.hip"]
 
 
 def hipcc() -> str:
@@ -60,9 +60,33 @@ def _stale() -> bool:
         return any(os.path.getmtime(d) > t for d in _deps())
 
 
+# Per-source extra flags.  attention.hip: no NaN ever enters the softmax (masked logits are -1e30, not -inf), and
+# without -fno-honor-nans every fmaxf of an MFMA result is preceded by a canonicalising v_max x,x,x.
+EXTRA_FLAGS = {"attention.hip": ["-fno-honor-nans"]}
+OBJ_DIR = os.path.join(PKG_DIR, "_build")
+
+
+def _common_flags():
+    return [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", CSRC, "-I", os.path.join(REPO_DIR, "include"),
+            "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form", *os.environ.get("VRWKV_EXTRA_HIPCC_FLAGS", "").split()]
+
+
+def _object_for(src: str, header_digest: str) -> tuple:
+    """(object path, compile command) of one source; the object name carries the hash of the source, every header and
+    the flags, so an unchanged source is not recompiled."""
+    flags = _common_flags() + EXTRA_FLAGS.get(os.path.basename(src), [])
+    h = hashlib.sha256(header_digest.encode())
+    with open(src, "rb") as f:
+        h.update(f.read())
+    h.update(" ".join(flags).encode())
+    obj = os.path.join(OBJ_DIR, f"{os.path.basename(src)}.{h.hexdigest()[:16]}.o")
+    return obj, [hipcc(), *flags, "-c", src, "-o", obj]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source into visualrwkv_amd/libvisualrwkv_hip.so for gfx950.  Safe to call from several
-    processes at once (one rank per GPU): a file lock lets one of them build, the library appears atomically."""
+    """Compile every HIP source into visualrwkv_amd/libvisualrwkv_hip.so for gfx950 (one object per source, compiled
+    in parallel, then linked).  Safe to call from several processes at once (one rank per GPU): a file lock lets one of
+    them build, the library appears atomically."""
     if not force and not _stale():
         return LIB_PATH
     with open(LIB_PATH + ".lock", "w") as lock:
@@ -70,10 +94,33 @@ def build(force: bool = False, verbose: bool = False) -> str:
         try:
             if not force and not _stale():       # another process built it while we waited
                 return LIB_PATH
+            from concurrent.futures import ThreadPoolExecutor
+            os.makedirs(OBJ_DIR, exist_ok=True)
+            hd = hashlib.sha256()
+            for d in _deps():
+                if d.endswith(".h"):
+                    with open(d, "rb") as f:
+                        hd.update(os.path.basename(d).encode() + f.read())
+            jobs = [_object_for(src, hd.hexdigest()) for src in _sources()]
+
+            def compile_one(job):
+                obj, cmd = job
+                if force or not os.path.exists(obj):
+                    if verbose:
+                        print(" ".join(cmd), file=sys.stderr)
+                    tmp_obj = f"{obj}.tmp{os.getpid()}"
+                    subprocess.run(cmd[:-1] + [tmp_obj], check=True)
+                    os.replace(tmp_obj, obj)
+                return obj
+
+            with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as pool:
+                objs = list(pool.map(compile_one, jobs))
+            keep = set(objs)
+            for f in os.listdir(OBJ_DIR):                      # objects of older source versions
+                if os.path.join(OBJ_DIR, f) not in keep:
+                    os.remove(os.path.join(OBJ_DIR, f))
             tmp = f"{LIB_PATH}.tmp{os.getpid()}"
-            cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-                   "-I", CSRC, "-I", os.path.join(REPO_DIR, "include"),
-                   "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form", *os.environ.get("VRWKV_EXTRA_HIPCC_FLAGS", "").split(), *_sources(), "-o", tmp]
+            cmd = [hipcc(), f"--offload-arch={ARCH}", "-fPIC", "-shared", *objs, "-o", tmp]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True)

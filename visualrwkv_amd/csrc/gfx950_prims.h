@@ -93,6 +93,14 @@ DEVFN float lane_xor32(float x) {
 }
 DEVFN float lane_bcast(float x, int src_lane) { return __shfl(x, src_lane, 64); }
 DEVFN int lane_id() { return (int)(threadIdx.x & 63); }
+// max of three: one v_max3_f32 when the compiler may assume no NaNs (attention.hip is built with -fno-honor-nans;
+// otherwise every fmaxf of an MFMA result gets a canonicalising v_max x,x,x first).  NOT inline asm on purpose: the
+// hazard recogniser does not look inside asm, and a VALU read of an in-flight MFMA result needs software wait states
+// -- an asm v_max3 straight on MFMA accumulators returned garbage on gfx950.
+DEVFN float max3_f32(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+DEVFN f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
+DEVFN bool wave_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0; }     // wave-uniform result
 // value is wave-uniform by construction (e.g. threadIdx.x >> 6): make that provable -> scalar branches
 DEVFN int uniform_i32(int x) { return __builtin_amdgcn_readfirstlane(x); }
 

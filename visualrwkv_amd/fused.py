@@ -594,3 +594,60 @@ class _LnScatter(torch.autograd.Function):
 
 def ln_scatter(embeds2d, y2d, ln, row_index):
     return _LnScatter.apply(embeds2d, y2d, ln.weight, ln.bias, row_index, ln.eps)
+
+
+# ------------------------------------------------------------------------------------------------
+# Patch embedding of the frozen towers (csrc/patch_embed_kernels.h)
+# ------------------------------------------------------------------------------------------------
+_PATCH_SIZES = (14, 16)
+
+
+def patch_embed_supported(x, patch, dim):
+    if not (visual_supported(x) and x.dim() == 4 and x.shape[1] == 3 and patch in _PATCH_SIZES and dim % 16 == 0):
+        return False
+    H, W = x.shape[-2:]
+    return H % patch == 0 and W % patch == 0 and ((H // patch) * (W // patch)) % 64 == 0
+
+
+def padded_patch_weight(weight):
+    """(N, 3, p, p) conv weight -> (N, KP) bf16 with zero columns up to the MFMA K multiple the kernel reads."""
+    N = weight.shape[0]
+    K = weight[0].numel()
+    KP = hip_lib.load().vrwkv_patch_embed_kp(int(weight.shape[-1]))
+    wp = torch.zeros(N, KP, dtype=torch.bfloat16, device=weight.device)
+    wp[:, :K] = weight.detach().reshape(N, K)
+    return wp
+
+
+def cached_padded_patch_weight(module, weight):
+    """The padded weight kept on the module that owns `weight` (frozen towers: built once); rebuilt when the parameter
+    is modified in place, replaced, or an optimizer step bumps the process-wide parameter generation."""
+    from . import param_state
+    key = (weight.data_ptr(), weight._version, param_state.generation(), tuple(weight.shape), weight.device)
+    hit = getattr(module, "_padded_patch_weight", None)
+    if hit is None or hit[0] != key:
+        hit = (key, padded_patch_weight(weight))
+        module._padded_patch_weight = hit
+    return hit[1]
+
+
+def patch_embed(x, weight, bias, pos=None, prefix=None, padded_weight=None):
+    """out[:, P:, :] = conv2d(x, weight, bias, stride=patch).flatten(2).T + pos; out[:, :P] = prefix tokens.
+    x (B,3,H,W) bf16; weight (N,3,p,p); bias (N) or None; pos (M,N) or None; prefix (P,N) or None (class / register
+    tokens, copied as they are).  Forward only (the towers are frozen, src/model.py:349,368)."""
+    B, _, H, W = x.shape
+    N, patch = weight.shape[0], weight.shape[-1]
+    M = (H // patch) * (W // patch)
+    npre = 0 if prefix is None else prefix.shape[0]
+    x = x.contiguous()
+    out = torch.empty(B, npre + M, N, dtype=torch.bfloat16, device=x.device)
+    if npre:
+        out[:, :npre] = prefix.to(torch.bfloat16)
+    wp = padded_weight if padded_weight is not None else padded_patch_weight(weight)
+    bias = None if bias is None else bias.detach().to(torch.bfloat16).contiguous()
+    pos = None if pos is None else pos.detach().to(torch.bfloat16).reshape(M, N).contiguous()
+    rc = hip_lib.load().vrwkv_patch_embed_bf16(B, H, W, patch, N, _p(x), _p(wp), None if bias is None else _p(bias),
+                                               None if pos is None else _p(pos), _p(out), npre + M, npre,
+                                               hip_lib.launch_stream(x.device))
+    hip_lib.check(rc, "vrwkv_patch_embed_bf16")
+    return out

@@ -51,6 +51,10 @@ PROTOTYPES = {
     "vrwkv_relusq_fwd_bf16": (_c_int, [ctypes.c_long] + [_c_void_p] * 3),
     "vrwkv_relusq_bwd_bf16": (_c_int, [ctypes.c_long] + [_c_void_p] * 4),
     "vrwkv_attention_fwd_bf16": (_c_int, [_c_int] * 4 + [_c_void_p] * 3 + [ctypes.c_long] * 3 + [_c_void_p] * 2),
+    "vrwkv_attention_relpos_fwd_bf16": (_c_int, [_c_int] * 4 + [_c_void_p] * 3 + [ctypes.c_long] * 3 + [_c_void_p] * 4),
+    "vrwkv_attention_set_qtiles": (_c_int, [_c_int]),
+    "vrwkv_patch_embed_bf16": (_c_int, [_c_int] * 5 + [_c_void_p] * 5 + [_c_int] * 2 + [_c_void_p]),
+    "vrwkv_patch_embed_kp": (_c_int, [_c_int]),
     "vrwkv_adamw_step_bf16": (_c_int, [ctypes.c_long] + [_c_void_p] * 5 + [ctypes.c_float] * 5 + [_c_int, ctypes.c_float, ctypes.c_long, ctypes.c_long, _c_void_p]),
     "vrwkv_adaptive_pool_bf16": (_c_int, [_c_int] * 4 + [_c_void_p] * 3),
     "vrwkv_gate_fwd_bf16": (_c_int, [_c_long] + [_c_void_p] * 4),

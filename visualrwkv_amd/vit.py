@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .attention import attention
+from .attention import attention, attention_relpos
 
 
 class _Mlp(nn.Module):
@@ -116,10 +116,19 @@ class TimmViT(nn.Module):
     def get_intermediate_layers(self, x, n: Sequence[int]):
         """Patch tokens after block index max(n) (0-based), prefix tokens removed, no final norm."""
         last = max(n)
-        x = self.patch_embed(x) + self.pos_embed
-        prefix = [t.expand(x.shape[0], -1, -1) for t in (self.cls_token, self.reg_token) if t is not None]
-        if prefix:
-            x = torch.cat(prefix + [x], dim=1)
+        from . import fused
+        pe = self.patch_embed
+        if (not torch.is_grad_enabled() or not pe.proj.weight.requires_grad) and pe.proj.weight.dtype == torch.bfloat16 \
+                and fused.patch_embed_supported(x, pe.patch, self.embed_dim):
+            # GPU: implicit GEMM over the NCHW pixels, bias + position embedding in the epilogue, prefix tokens in place
+            pre = [t[0] for t in (self.cls_token, self.reg_token) if t is not None]
+            x = fused.patch_embed(x, pe.proj.weight, pe.proj.bias, self.pos_embed[0], torch.cat(pre, dim=0) if pre else None,
+                                  padded_weight=fused.cached_padded_patch_weight(pe, pe.proj.weight))
+        else:
+            x = pe(x) + self.pos_embed
+            prefix = [t.expand(x.shape[0], -1, -1) for t in (self.cls_token, self.reg_token) if t is not None]
+            if prefix:
+                x = torch.cat(prefix + [x], dim=1)
         for i, blk in enumerate(self.blocks):
             x = blk(x)
             if i == last:
@@ -162,15 +171,6 @@ class _SamMlp(nn.Module):
         return self.lin2(F.gelu(self.lin1(x)))
 
 
-def _rel_table(size: int, rel_pos: torch.Tensor) -> torch.Tensor:
-    """(size, size, C) table R[q, k] = rel_pos[q - k + size - 1]  (src/sam.py:359-389, equal q/k sizes)."""
-    want = 2 * size - 1
-    if rel_pos.shape[0] != want:
-        rel_pos = F.interpolate(rel_pos.t()[None], size=want, mode="linear")[0].t()
-    idx = torch.arange(size, device=rel_pos.device)
-    return rel_pos[(idx[:, None] - idx[None, :]) + (size - 1)]
-
-
 class _SamAttention(nn.Module):
     def __init__(self, dim, heads, input_size):
         super().__init__()
@@ -186,12 +186,8 @@ class _SamAttention(nn.Module):
         nh, hd = self.num_heads, C // self.num_heads
         qkv = self.qkv(x).view(B, Hh * Ww, 3, nh, hd)
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]                 # (B, L, nh, hd)
-        # decomposed relative position bias (src/sam.py:392-426), computed from the *unscaled* q
-        rq = q.reshape(B, Hh, Ww, nh, hd)
-        rel_h = torch.einsum("bhwnc,hkc->bnhwk", rq, _rel_table(Hh, self.rel_pos_h).to(q.dtype))
-        rel_w = torch.einsum("bhwnc,wkc->bnhwk", rq, _rel_table(Ww, self.rel_pos_w).to(q.dtype))
-        bias = (rel_h[..., :, None] + rel_w[..., None, :]).reshape(B, nh, Hh * Ww, Hh * Ww)
-        o = attention(q, k, v, bias=bias)
+        # decomposed relative position bias (src/sam.py:392-426), from the *unscaled* q: inside the MFMA kernel on the GPU
+        o = attention_relpos(q, k, v, self.rel_pos_h, self.rel_pos_w, (Hh, Ww))
         return self.proj(o.reshape(B, Hh, Ww, C))
 
 
@@ -254,7 +250,15 @@ class SamImageEncoder(nn.Module):
         self.output_dim = out_chans * 4
 
     def forward(self, x):
-        x = self.patch_embed(x) + self.pos_embed
+        from . import fused
+        pe = self.patch_embed
+        if (not torch.is_grad_enabled() or not pe.proj.weight.requires_grad) and pe.proj.weight.dtype == torch.bfloat16 \
+                and fused.patch_embed_supported(x, pe.patch, pe.proj.weight.shape[0]):
+            g = x.shape[-1] // pe.patch
+            x = fused.patch_embed(x, pe.proj.weight, pe.proj.bias, self.pos_embed[0].reshape(g * g, -1),
+                                  padded_weight=fused.cached_padded_patch_weight(pe, pe.proj.weight)).view(x.shape[0], g, g, -1)
+        else:
+            x = pe(x) + self.pos_embed
         for blk in self.blocks:
             x = blk(x)
         x = self.neck(x.permute(0, 3, 1, 2))
