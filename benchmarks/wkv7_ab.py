@@ -1,5 +1,5 @@
-"""Same-process A/B of kernel variants (interleaved, best of several rounds): python benchmarks/wkv7_ab.py --B 8 16
---bwd 2 3 4 5 --fwd -1"""
+"""Same-process A/B of the kernel generations (interleaved, best of several rounds):
+python benchmarks/wkv7_ab.py --B 8 16 --bwd 4 -1 --fwd 0 -1   (4 / 0 = the predecessors kept for comparison)"""
 import argparse
 import json
 import os

@@ -8,7 +8,6 @@ from visualrwkv_amd import hip_lib
 
 FWD = ["c_top", "c_main1", "c_waitA", "c_store_y_sa", "c_supdate_store_s", "c_waitB", "-", "-", "p_prep", "p_waitA", "p_scores", "p_waitB"]
 BWD5 = ["c_top", "c_isplit", "c_waitX", "c_jsplit", "c_waitY", "c_seg3_tail", "c_waitZ", "-", "p_top", "p_prepA", "p_waitX", "p_prepB", "p_dM", "p_waitY", "p_scores", "p_waitZ"]
-BWD = ["c_isplit", "c_waitX", "c_jsplit", "c_waitY", "c_tail_waitZ", "c_start", "-", "-", "p_start", "p_prepA_waitX", "p_prepB", "p_flagwait", "p_dM_waitY", "p_scores_waitZ"]
 
 def run(B=8, T=2624, H=32, bwd_variant=-1, fwd_variant=-1):
     lib = hip_lib.load()
@@ -20,7 +19,7 @@ def run(B=8, T=2624, H=32, bwd_variant=-1, fwd_variant=-1):
     g = [torch.empty_like(w) for _ in range(6)]
     st = torch.cuda.current_stream().cuda_stream
     out = {}
-    for bw, names in ((0, FWD), (1, BWD5 if bwd_variant in (-1, 7, 8) else BWD)):
+    for bw, names in ((0, FWD), (1, BWD5)):
         dbg = torch.zeros(16, dtype=torch.int64, device=dev)
         rc = lib.vrwkv_wkv7_profile_bf16(bw, B, T, H, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), z.data_ptr(), a.data_ptr(),
                                          dy.data_ptr(), y.data_ptr(), s.data_ptr(), sa.data_ptr(), *[x.data_ptr() for x in g], dbg.data_ptr(), st)

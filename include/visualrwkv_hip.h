@@ -149,17 +149,12 @@ int vrwkv_decode_tmix_head_bf16(int B, int H, const void* r, const void* k, cons
 int vrwkv_wkv7_step_bf16(int B, int H, const void* w, const void* q, const void* k, const void* v,
                          const void* z, const void* a, float* state, void* y, void* stream);
 
-/* Launch-shape override for benchmarking/tests: variant < 0 restores the automatic choice.
- * forward variants: 0/1/2 = sequential VALU kernel with 1/2/4 waves per head, 3 = chunked bf16x3 MFMA kernel
- * (4 waves, phases back to back), 4..7 = chunked MFMA kernel with producer/consumer wave specialisation
- * (4: 16-byte stores + producer priority, 5: scalar stores + priority [default], 6/7: same without priority,
- * 8: 5 + two chunks of input prefetch, 9: 5 + DPP suffix scan, 10: both, 11: 5 + ds_read_b64_tr_b16 operand reads
- * instead of transposed LDS copies; 8..11 measured within +-2 % of 5 on MI355X). */
+/* Kernel-generation override for tests and A/B benchmarks; -1 restores the default.
+ * forward:  -1 = chunked MFMA kernel with producer / consumer waves (csrc/wkv7_fwd_v3.h),
+ *            0 = its predecessor, the sequential one-wave-per-head kernel (csrc/wkv7_kernels.h).
+ * backward: -1 = second-generation producer / consumer schedule (csrc/wkv7_bwd_v5.h),
+ *            4 = its predecessor (csrc/wkv7_bwd_v3.h).  Anything else: VRWKV_EINVAL. */
 int vrwkv_wkv7_set_forward_variant(int variant);
-/* backward variants: 0 = sequential VALU kernel, 1 = chunked bf16x3 MFMA kernel (4 waves, phases back to back),
- * 2..5 = chunked MFMA kernel with producer/consumer wave specialisation: 2 workgroup barriers + f32 doubling for T,
- * 3 LDS hand-off counters instead of barriers, 4 barriers + bf16x3 doubling [default], 5 counters + bf16x3,
- * 6 = 12-wave kernel with the consumer work split by role (wkv7_bwd_v4.h; 12 % slower: the SIMDs are issue-bound). */
 int vrwkv_wkv7_set_backward_variant(int variant);
 
 /* ---- Fused element-wise glue of RWKV_Tmix_x070 / RWKV_CMix_x070 (VisualRWKV-v7/v7.00/src/model.py), forward and

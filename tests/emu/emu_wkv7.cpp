@@ -6,9 +6,7 @@
 #include <wkv7_chunked_bwd.h>
 #include <wkv7_fwd_v3.h>
 #include <wkv7_bwd_v3.h>
-#include <wkv7_bwd_v4.h>
 #include <wkv7_bwd_v5.h>
-#include <wkv7_fwd_v5.h>
 #include <wkv6_chunked.h>
 
 extern "C" {
@@ -18,16 +16,8 @@ int emu_wkv7_forward(int B, int T, int H, const void* w, const void* q, const vo
     wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                     (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, s, sa};
     dim3 grid((unsigned)(B * H));
-    if (variant == 0) emu::launch(grid, dim3(64), [&] { wkv7::fwd_kernel<16, 8>(p); });
-    else if (variant == 1) emu::launch(grid, dim3(128), [&] { wkv7::fwd_kernel<8, 16>(p); });
-    else if (variant == 2) emu::launch(grid, dim3(256), [&] { wkv7::fwd_kernel<4, 16>(p); });
-    else if (variant == 3) emu::launch(grid, dim3(256), [&] { wkv7c::fwd_kernel_t<false>(p); });
-    else if (variant == 4) emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false>(p); });                       // wide stores
-    else if (variant == 5) emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1>(p); });             // narrow stores
-    else if (variant == 12) emu::launch(grid, dim3(512), [&] { wkv7v5::fwd_kernel_v5<false, 0>(p); });                  // second-generation schedule
-    else if (variant == 13) emu::launch(grid, dim3(512), [&] { wkv7v5::fwd_kernel_v5<false, 2>(p); });
-    else if (variant == 10) emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1, 2, true>(p); });  // + prefetch 2, DPP suffix
-    else emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1, 1, false, true>(p); });              // transpose reads
+    if (variant == 0) emu::launch(grid, dim3(64), [&] { wkv7::fwd_kernel<16, 8>(p); });                 // scalar predecessor
+    else emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1>(p); });               // default
     return 0;
 }
 
@@ -39,35 +29,19 @@ int emu_wkv7_forward_state(int B, int T, int H, const void* w, const void* q, co
     return 0;
 }
 
-int emu_wkv7_backward(int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
-                      const void* z, const void* a, const void* dy, const float* s, const float* sa,
-                      void* dw, void* dq, void* dk, void* dv, void* dz, void* da) {
-    wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
-                    (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
-                    (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
-    emu::launch(dim3((unsigned)(B * H)), dim3(256), [&] { wkv7::bwd_kernel<8>(p); });
-    return 0;
-}
-
 int emu_wkv7_backward_chunked(int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
                               const void* z, const void* a, const void* dy, const float* s, const float* sa,
                               void* dw, void* dq, void* dk, void* dv, void* dz, void* da, int mode) {
-    // mode -1: 4-wave kernel (wkv7_chunked_bwd.h); 0..3: 8-wave kernel, bit 0 = hand-off counters, bit 1 = bf16x3 doubling
+    // mode 2: predecessor (wkv7_bwd_v3.h, bf16x3 doubling); 6: default (wkv7_bwd_v5.h, T chain on the bf16 matrix core)
     wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                     (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
                     (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
-    static_assert(sizeof(wkv7c::LdsB) <= 160 * 1024, "LDS budget");
     static_assert(sizeof(wkv7c::LdsB3) <= 160 * 1024, "LDS budget");
+    static_assert(sizeof(wkv7v5::LdsV5) <= 160 * 1024, "LDS budget");
     const dim3 grid((unsigned)(B * H));
-    if (mode < 0) emu::launch(grid, dim3(256), [&] { wkv7c::bwd_kernel_t<false>(p); });
-    else if (mode == 0) emu::launch(grid, dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 0>(p); });
-    else if (mode == 1) emu::launch(grid, dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 1>(p); });
-    else if (mode == 2) emu::launch(grid, dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 2>(p); });
-    else if (mode == 3) emu::launch(grid, dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 3>(p); });
-    else if (mode == 4) emu::launch(grid, dim3(768), [&] { wkv7c::bwd_kernel_v4<false>(p); });
-    else if (mode == 5) { emu::launch(grid, dim3(512), [&] { wkv7v5::bwd_kernel_v5<false, 2>(p); }); return (int)sizeof(wkv7v5::LdsV5); }
-    else { emu::launch(grid, dim3(512), [&] { wkv7v5::bwd_kernel_v5<false, 0>(p); }); return (int)sizeof(wkv7v5::LdsV5); }
-    return (int)sizeof(wkv7c::LdsB3);
+    if (mode == 2) { emu::launch(grid, dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 2>(p); }); return (int)sizeof(wkv7c::LdsB3); }
+    if (mode == 6) { emu::launch(grid, dim3(512), [&] { wkv7v5::bwd_kernel_v5<false, 6>(p); }); return (int)sizeof(wkv7v5::LdsV5); }
+    return -1;
 }
 
 int emu_wkv6_forward(int B, int T, int H, const void* r, const void* k, const void* v, const float* ew, const void* u,
@@ -100,18 +74,6 @@ extern "C" int emu_wgrad_skinny(long M, int Nw, int D, int S, const void* wide, 
     return 0;
 }
 
-extern "C" int emu_wkv7_backward_segments(int B, int T, int H, int nseg, const void* w, const void* q, const void* k, const void* v,
-                                          const void* z, const void* a, const void* dy, const float* s, const float* sa,
-                                          const float* ds_in, float* ds_out,
-                                          void* dw, void* dq, void* dk, void* dv, void* dz, void* da) {
-    wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
-                    (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
-                    (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
-    p.ds_in = ds_in; p.ds_out = ds_out; p.nseg = nseg;
-    emu::launch(dim3((unsigned)(B * H * nseg)), dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 2, true>(p); });
-    return 0;
-}
-
 extern "C" int emu_wkv7_backward_segments_v5(int B, int T, int H, int nseg, const void* w, const void* q, const void* k, const void* v,
                                              const void* z, const void* a, const void* dy, const float* s, const float* sa,
                                              const float* ds_in, float* ds_out,
@@ -120,7 +82,7 @@ extern "C" int emu_wkv7_backward_segments_v5(int B, int T, int H, int nseg, cons
                     (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
                     (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
     p.ds_in = ds_in; p.ds_out = ds_out; p.nseg = nseg;
-    emu::launch(dim3((unsigned)(B * H * nseg)), dim3(512), [&] { wkv7v5::bwd_kernel_v5<false, 0, true>(p); });
+    emu::launch(dim3((unsigned)(B * H * nseg)), dim3(512), [&] { wkv7v5::bwd_kernel_v5<false, 6, true>(p); });
     return 0;
 }
 
@@ -130,23 +92,5 @@ extern "C" int emu_wkv7_forward_state_train(int B, int T, int H, const void* w, 
     wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                     (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, s_ckpt, sa, nullptr, s0, s_final};
     emu::launch(dim3((unsigned)(B * H)), dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1>(p); });
-    return 0;
-}
-
-extern "C" int emu_wkv7_backward_v5_dump(int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
-                                         const void* z, const void* a, const void* dy, const float* s, const float* sa,
-                                         void* dw, void* dq, void* dk, void* dv, void* dz, void* da, void* dbg) {
-    wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
-                    (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
-                    (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da, (unsigned long long*)dbg};
-    emu::launch(dim3((unsigned)(B * H)), dim3(512), [&] { wkv7v5::bwd_kernel_v5<false, 0, false, true>(p); });
-    return 0;
-}
-
-extern "C" int emu_wkv7_forward_state_v5(int B, int T, int H, const void* w, const void* q, const void* k, const void* v, const void* z,
-                                         const void* a, void* y, const float* s0, float* s_final, float* s_ckpt, float* sa) {
-    wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
-                    (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, s_ckpt, sa, nullptr, s0, s_final};
-    emu::launch(dim3((unsigned)(B * H)), dim3(512), [&] { wkv7v5::fwd_kernel_v5<false, 0>(p); });
     return 0;
 }

@@ -1,4 +1,4 @@
-"""Sequence-parallel WKV7 backward (bwd_kernel_v3<.., TPAR>) on the host emulator: two passes over the segments with a
+"""Sequence-parallel WKV7 backward (bwd_kernel_v5<.., TPAR>) on the host emulator: two passes over the segments with a
 64x64 scan in between reproduce the gradients of the plain chunk-sequential backward kernel."""
 import ctypes
 
@@ -12,18 +12,17 @@ def P(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
-@pytest.mark.parametrize("gen", ["v3", "v5"])
 @pytest.mark.parametrize("T,H,nseg", [(96, 2, 3), (64, 1, 4), (80, 1, 2)])
-def test_two_pass_segments_equal_sequential_backward(emu_lib, T, H, nseg, gen):
+def test_two_pass_segments_equal_sequential_backward(emu_lib, T, H, nseg):
     B = 1
-    segments = emu_lib.emu_wkv7_backward_segments if gen == "v3" else emu_lib.emu_wkv7_backward_segments_v5
-    seq_mode = 2 if gen == "v3" else 6
+    segments = emu_lib.emu_wkv7_backward_segments_v5
+    seq_mode = 6
     w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=T + nseg)
     y = torch.zeros_like(v)
     nch = T // 16
     s = torch.zeros(B, H, nch, 64, 64)
     sa = torch.zeros(B, T, H, 64)
-    emu_lib.emu_wkv7_forward(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(y), P(s), P(sa), 5)
+    emu_lib.emu_wkv7_forward(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(y), P(s), P(sa), -1)
     ref = [torch.zeros_like(w) for _ in range(6)]
     emu_lib.emu_wkv7_backward_chunked(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(dy), P(s), P(sa), *[P(t) for t in ref], seq_mode)
 
@@ -53,8 +52,7 @@ def test_two_pass_segments_equal_sequential_backward(emu_lib, T, H, nseg, gen):
         assert rel_rms(a_.float(), b_.float()) < 2e-3, name      # bf16 outputs; state products in bf16x3
 
 
-@pytest.mark.parametrize("gen", ["v3", "v5"])
-def test_host_function_on_the_emulator(emu_lib, monkeypatch, gen):
+def test_host_function_on_the_emulator(emu_lib, monkeypatch):
     """visualrwkv_amd.wkv7.wkv7_backward_tparallel itself (segment views, M_p, scan, two launches), with the two C-ABI
     entries it calls redirected to the emulated kernels -- the host logic cannot run on a GPU in this suite."""
     import contextlib
@@ -72,7 +70,7 @@ def test_host_function_on_the_emulator(emu_lib, monkeypatch, gen):
 
         @staticmethod
         def vrwkv_wkv7_backward_segments_bf16(B, T, H, P_, w, q, k, v, z, a, dy, s, sa, ds_in, ds_out, dw, dq, dk, dv, dz, da, stream):
-            fn = emu_lib.emu_wkv7_backward_segments if gen == "v3" else emu_lib.emu_wkv7_backward_segments_v5
+            fn = emu_lib.emu_wkv7_backward_segments_v5
             return fn(B, T, H, P_, V(w), V(q), V(k), V(v), V(z), V(a), V(dy), V(s), V(sa), V(ds_in), V(ds_out), V(dw), V(dq), V(dk), V(dv),
                       V(dz), V(da))
 
@@ -88,9 +86,9 @@ def test_host_function_on_the_emulator(emu_lib, monkeypatch, gen):
     y = torch.zeros_like(v)
     s = torch.zeros(B, H, T // 16, 64, 64)
     sa = torch.zeros(B, T, H, 64)
-    emu_lib.emu_wkv7_forward(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(y), P(s), P(sa), 5)
+    emu_lib.emu_wkv7_forward(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(y), P(s), P(sa), -1)
     ref = [torch.zeros_like(w) for _ in range(6)]
-    emu_lib.emu_wkv7_backward_chunked(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(dy), P(s), P(sa), *[P(t) for t in ref], 2 if gen == "v3" else 6)
+    emu_lib.emu_wkv7_backward_chunked(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(dy), P(s), P(sa), *[P(t) for t in ref], 6)
     got = wkv7.wkv7_backward_tparallel(w, q, k, v, z, a, dy, s, sa, nseg)
     for name, a_, b_ in zip(("dw", "dq", "dk", "dv", "dz", "da"), got, ref):
         assert rel_rms(a_.float(), b_.float()) < 2e-3, name

@@ -14,10 +14,10 @@ def P(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 10, 11, 12, 13])
+@pytest.mark.parametrize("variant", [0, -1])        # scalar predecessor, chunked MFMA default
 def test_forward_variants(emu_lib, variant):
     B, T, H, N = 2, 32, 2, 64
-    w, q, k, v, z, a, _ = make_inputs(B, T, H, seed=variant)
+    w, q, k, v, z, a, _ = make_inputs(B, T, H, seed=variant + 1)
     yr, sr, sar = wkv7_c.forward(w, q, k, v, z, a)
     y = torch.zeros_like(yr); s = torch.zeros_like(sr); sa = torch.zeros_like(sar)
     emu_lib.emu_wkv7_forward(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(y), P(s), P(sa), variant)
@@ -44,22 +44,10 @@ def test_forward_from_state(emu_lib):
     assert rel_rms(y2.double(), y_ref0) < 4e-3
 
 
-def test_backward(emu_lib):
-    B, T, H, N = 1, 48, 2, 64
-    w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=5)
-    _, s, sa = wkv7_c.forward(w, q, k, v, z, a)
-    ref = wkv7_c.backward(w, q, k, v, z, a, dy, s, sa)
-    outs = [torch.zeros_like(w) for _ in range(6)]
-    emu_lib.emu_wkv7_backward(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(dy), P(s), P(sa), *[P(o) for o in outs])
-    for name, o, r in zip(["dw", "dq", "dk", "dv", "dz", "da"], outs, ref):
-        assert rel_rms(o.float(), r.float()) < 1e-3, name
-
-
-@pytest.mark.parametrize("mode", [-1, 0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("mode", [2, 6])
 def test_backward_chunked(emu_lib, mode):
-    """Chunked MFMA backward kernels run lane-exactly on the host: the 4-wave kernel (-1) and the 8-wave
-    producer/consumer kernel with workgroup barriers or LDS hand-off counters (bit 0) and f32 / bf16x3 doubling (bit 1);
-    5 / 6: second-generation schedule (wkv7_bwd_v5.h) with bf16x3 / f32 doubling."""
+    """Chunked MFMA backward kernels run lane-exactly on the host: 2 = the predecessor (wkv7_bwd_v3.h, workgroup barriers,
+    bf16x3 doubling), 6 = the default second-generation schedule (wkv7_bwd_v5.h)."""
     B, T, H = 1, 48, 2
     w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=7 + mode)
     _, s, sa = wkv7_c.forward(w, q, k, v, z, a)

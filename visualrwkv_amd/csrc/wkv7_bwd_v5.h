@@ -280,8 +280,7 @@ DEVFN void tiles_op(const f32x4* tl, bf16x8* oh, bf16x8* ol) {
 // MODE bit 1: T doubling on the bf16 matrix core (split operands) instead of the f32 one.
 // TPAR: sequence-parallel launch (see wkv7_bwd_v3.h): blockIdx.x = (b*H + h) * nseg + seg, chunks [c_lo, c_hi),
 // dL/dS enters as ds_in[b,h,seg] and leaves as ds_out[b,h,seg] (both [i][j] fp32).
-// DUMP: register snapshots of workgroup 0 into p.dbg (debugging aid, compared with the host emulator's).
-template <bool PROF, int MODE = 0, bool TPAR = false, bool DUMP = false>
+template <bool PROF, int MODE = 0, bool TPAR = false>
 __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
     LdsV5& lds = *reinterpret_cast<LdsV5*>(dyn_lds());
     const int T = p.T, H = p.H;
@@ -363,13 +362,6 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
     // ====================================================================== consumers (stores only inside the loop)
     const LaneAddr la = lane_addr(c16, g, wave);
     const int j = 16 * wave + c16;                      // key column of the j-split tiles
-    int dump_it = 0;
-    auto dump = [&](int slot, f32x4 v) {
-        if (DUMP && blockIdx.x == 0 && dump_it < 2) {
-            float* d = reinterpret_cast<float*>(p.dbg) + ((size_t)(dump_it * 32 + slot) * 256 + tid) * 4;
-            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
-        }
-    };
     f32x4 dS1[4], dS2[4];
 #pragma unroll
     for (int x = 0; x < 4; ++x) { dS1[x] = zero4(); dS2[x] = zero4(); }
@@ -482,7 +474,6 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
             bf16x8 s0h[2], s0l[2], duh[2], dul[2];
             tiles_op(S0, s0h, s0l);
             tiles_op(dU, duh, dul);
-            if (DUMP) { for (int ib = 0; ib < 4; ++ib) { dump(ib, S0[ib]); dump(4 + ib, dU[ib]); } }
             // transposed results: D[m = j][n = t]  (lane = token, registers = 4 consecutive channels of the wave's 16)
             {
                 const bf16x8 drh = ld16(&lds.dr[0][la.row[0]]);
@@ -516,7 +507,6 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
                 dKh = mfma32(duh[1], vr, dKh);
                 dKh = mfma32(dul[1], vr, dKh);
             }
-            if (DUMP) { dump(8, dZt); dump(9, dQt); dump(10, dAh); dump(11, dKh); }
             // dS <- dU + [dY^T | dR^T] [Qt ; Zt]
             qzh = mk8(lds_read_tr16(&B.opnd[2][la.trc]), lds_read_tr16(&B.opnd[0][la.trc]));
             qzl = mk8(lds_read_tr16(&B.opnd[3][la.trc]), lds_read_tr16(&B.opnd[1][la.trc]));
@@ -537,7 +527,6 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gl = fmaf(acc[r], S0[ib][r], gl);       // S0 of this chunk = S_L of the next one
             }
-            if (DUMP) { for (int ib = 0; ib < 4; ++ib) dump(12 + ib, dS2[ib]); }
             gl += lane_xor16(gl);
             gl += lane_xor32(gl);
             if (g == 0) lds.b[(c - 1) & 1].glast[j] = gl;
@@ -600,7 +589,6 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
             *reinterpret_cast<uint2*>(p.dz + o) = make_uint2(cvt_pk_bf16(dz[0], dz[1]), cvt_pk_bf16(dz[2], dz[3]));
             *reinterpret_cast<uint2*>(p.da + o) = make_uint2(cvt_pk_bf16(da[0], da[1]), cvt_pk_bf16(da[2], da[3]));
         }
-        if (DUMP) { dump(18, dZt); dump(19, dQt); dump(20, dAh); dump(21, dKh); ++dump_it; }
         WKV_STAMP(5)
         block_sync_lds();                                   // Z
         WKV_STAMP(6)

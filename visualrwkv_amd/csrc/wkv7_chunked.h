@@ -208,111 +208,6 @@ DEVFN bf16x8 ld_perm(const uint16_t (*M)[TJ], int row, int kb, int g) {
         for (int i_ = 0; i_ < (n); ++i_) p.dbg[(base) + i_] = tacc_[i_];       \
     }
 
-template <bool PROF>
-__global__ __launch_bounds__(256) void fwd_kernel_t(FwdArgs p) {
-    __shared__ __attribute__((aligned(16))) Lds lds;
-    WKV_STAMP_DECL
-    const int T = p.T, H = p.H;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int c16 = lane & 15, g = lane >> 4;
-    const size_t head_base = ((size_t)b * T * H + h) * N;
-    const size_t tstride = (size_t)H * N;
-    // phase-1 address of this lane inside a chunk: token c16, columns 16*wave + 4g
-    const size_t prep_off = head_base + (size_t)c16 * tstride + 16 * wave + 4 * g;
-
-    f32x4 S[4];                           // S^T tiles: S[jb][r] = S^T[j = 16jb+4g+r][i = 16*wave + c16]
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb) S[jb] = zero4();
-
-    RawChunk rc;
-    load_chunk(rc, p, prep_off);
-    const int nchunk = T / L;
-    for (int c = 0; c < nchunk; ++c) {
-        prep(lds, rc, wave, lane);
-        if (c + 1 < nchunk) load_chunk(rc, p, prep_off + (size_t)(c + 1) * L * tstride);
-        WKV_STAMP(0)
-        block_sync_lds();
-        WKV_STAMP(1)
-        scores(lds, wave, lane);
-        WKV_STAMP(2)
-        block_sync_lds();
-        WKV_STAMP(3)
-
-        // ---------------- phase 3
-        uint2 sh[4], sl[4];
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) split4(S[jb], sh[jb], sl[jb]);
-        const bf16x8 bsh[2] = {mk8(sh[0], sh[1]), mk8(sh[2], sh[3])};
-        const bf16x8 bsl[2] = {mk8(sl[0], sl[1]), mk8(sl[2], sl[3])};
-        const uint2 vv = ld8(&lds.vt[16 * wave + c16][4 * g]);
-        const bf16x8 bvv = mk8(vv, vv);
-
-        // R = M_zk V + Zt S0^T
-        f32x4 R = mfma_16x16x32_bf16(mk8(ld8(&lds.sc[0][0][c16][4 * g]), ld8(&lds.sc[0][1][c16][4 * g])), bvv, zero4());
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const bf16x8 zh = ld_perm(lds.opnd[0], c16, kb, g), zl = ld_perm(lds.opnd[1], c16, kb, g);
-            R = mfma_16x16x32_bf16(zh, bsh[kb], R);
-            R = mfma_16x16x32_bf16(zh, bsl[kb], R);
-            R = mfma_16x16x32_bf16(zl, bsh[kb], R);
-        }
-        // SA = T R
-        uint2 rh, rl;
-        split4(R, rh, rl);
-        const uint2 th = ld8(&lds.sc[3][0][c16][4 * g]), tl = ld8(&lds.sc[3][1][c16][4 * g]);
-        f32x4 SA = mfma_16x16x32_bf16(mk8(th, th), mk8(rh, rl), zero4());
-        SA = mfma_16x16x32_bf16(mk8(tl.x, tl.y, 0u, 0u), mk8(rh.x, rh.y, 0u, 0u), SA);
-        uint2 sah, sal;
-        split4(SA, sah, sal);
-        // Y = M_qk V + Qt S0^T + M_qa SA
-        f32x4 Y = mfma_16x16x32_bf16(mk8(ld8(&lds.sc[2][0][c16][4 * g]), ld8(&lds.sc[2][1][c16][4 * g])), bvv, zero4());
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const bf16x8 qh = ld_perm(lds.opnd[2], c16, kb, g), ql = ld_perm(lds.opnd[3], c16, kb, g);
-            Y = mfma_16x16x32_bf16(qh, bsh[kb], Y);
-            Y = mfma_16x16x32_bf16(qh, bsl[kb], Y);
-            Y = mfma_16x16x32_bf16(ql, bsh[kb], Y);
-        }
-        {
-            const uint2 mh = ld8(&lds.sc[1][0][c16][4 * g]), ml = ld8(&lds.sc[1][1][c16][4 * g]);
-            Y = mfma_16x16x32_bf16(mk8(mh, mh), mk8(sah, sal), Y);
-            Y = mfma_16x16x32_bf16(mk8(ml.x, ml.y, 0u, 0u), mk8(sah.x, sah.y, 0u, 0u), Y);
-        }
-        // outputs of this chunk: rows t = 4g + r, column i = 16*wave + c16
-        {
-            const size_t o = head_base + (size_t)(c * L + 4 * g) * tstride + 16 * wave + c16;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                p.sa[o + r * tstride] = SA[r];
-                p.y[o + r * tstride] = (uint16_t)f32_to_bf16_bits(Y[r]);
-            }
-        }
-        // S_L^T = diag(c_L) S0^T + [Ab^T | Kb^T] [SA ; V]
-        const bf16x8 b1 = mk8(sah, vv), b2 = mk8(sal.x, sal.y, 0u, 0u);
-        float* sdst = p.s + (((size_t)blockIdx.x * nchunk + c) * N) * N + 16 * wave + c16;
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
-            const float4 cl = *reinterpret_cast<const float4*>(&lds.cl[16 * jb + 4 * g]);
-            f32x4 acc = S[jb];
-            acc[0] *= cl.x; acc[1] *= cl.y; acc[2] *= cl.z; acc[3] *= cl.w;
-            const int j = 16 * jb + c16;
-            const bf16x8 ah = mk8(ld8(&lds.trn[0][j][4 * g]), ld8(&lds.trn[2][j][4 * g]));
-            const bf16x8 al = mk8(ld8(&lds.trn[1][j][4 * g]), ld8(&lds.trn[3][j][4 * g]));
-            acc = mfma_16x16x32_bf16(ah, b1, acc);
-            acc = mfma_16x16x32_bf16(ah, b2, acc);
-            acc = mfma_16x16x32_bf16(al, b1, acc);
-            S[jb] = acc;
-            // checkpoint s[b,h,c,j,i] = S[i][j] = S^T[j][i]
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sdst[(size_t)(16 * jb + 4 * g + r) * N] = acc[r];
-        }
-        WKV_STAMP(4)
-        block_sync_lds();
-        WKV_STAMP(5)
-    }
-    WKV_STAMP_FLUSH(0, 0, 6)
-}
 
 
 }  // namespace wkv7c

@@ -190,201 +190,5 @@ struct BwdArgs {
     int nseg = 1;
 };
 
-// One workgroup (4 waves) per head; wave `wv` owns state rows [16 wv, 16 wv + 16).  The backward
-// recurrence is row-separable once sa is given (S un-step, dS propagation, dv and dsa only need a
-// lane's own rows); the five column-indexed outputs (dq dw dk da dz) are sums over rows that never
-// feed back, so they are reduced across lanes/waves off the critical path (LDS partials).
-// Lane = rg*16 + cg: rows 4rg..4rg+3 of the wave's 16, columns 4cg..4cg+3.
-template <int SC>
-__global__ __launch_bounds__(256) void bwd_kernel(BwdArgs p) {
-    constexpr int NT = 256;
-    // LDS input vectors per step: 0 w(decay) 1 q 2 k 3 v 4 z 5 a 6 dy 7 sa 8 wscale(= w * -exp(w_raw))
-    constexpr int NIN = 9;
-    constexpr int NOUT = 5;                 // 0 dw 1 dq 2 dk 3 da(op) 4 dz(op)
-    __shared__ __attribute__((aligned(16))) float lin[SC][NIN][N];
-    __shared__ __attribute__((aligned(16))) float part[SC][NOUT][4][N];
-
-    const int T = p.T, H = p.H;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int cg = lane & 15, rg = lane >> 4;
-    const int row0 = wave * 16 + rg * 4, col0 = cg * 4;
-    const size_t head_base = ((size_t)b * T * H + h) * N;
-    const size_t tstride = (size_t)H * N;
-
-    float S[4][4], dS[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { S[r][j] = 0.f; dS[r][j] = 0.f; }
-
-    constexpr int BSEG = SC * 7 * 8;                    // 16-byte bf16 segments (7 vectors)
-    constexpr int BLOADS = (BSEG + NT - 1) / NT;
-    constexpr int FSEG = SC * 16;                       // 16-byte f32 segments of sa
-    static_assert(FSEG <= NT, "sa segments");
-    uint4 pre[BLOADS];
-    float4 presa;
-
-    auto issue = [&](int t0) {
-#pragma unroll
-        for (int i = 0; i < BLOADS; ++i) {
-            const int g = i * NT + tid;
-            if (g < BSEG) {
-                const int vec = g / (SC * 8), rem = g % (SC * 8), step = rem >> 3, seg = rem & 7;
-                const uint16_t* src = vec == 0 ? p.w : vec == 1 ? p.q : vec == 2 ? p.k : vec == 3 ? p.v
-                                     : vec == 4 ? p.z : vec == 5 ? p.a : p.dy;
-                pre[i] = *reinterpret_cast<const uint4*>(src + head_base + (size_t)(t0 + step) * tstride + seg * 8);
-            }
-        }
-        if (tid < FSEG) {
-            const int step = tid >> 4, seg = tid & 15;
-            presa = *reinterpret_cast<const float4*>(p.sa + head_base + (size_t)(t0 + step) * tstride + seg * 4);
-        }
-    };
-    auto park = [&]() {
-#pragma unroll
-        for (int i = 0; i < BLOADS; ++i) {
-            const int g = i * NT + tid;
-            if (g < BSEG) {
-                const int vec = g / (SC * 8), rem = g % (SC * 8), step = rem >> 3, seg = rem & 7;
-                float f[8] = {bf16_lo(pre[i].x), bf16_hi(pre[i].x), bf16_lo(pre[i].y), bf16_hi(pre[i].y),
-                              bf16_lo(pre[i].z), bf16_hi(pre[i].z), bf16_lo(pre[i].w), bf16_hi(pre[i].w)};
-                if (vec == 0) {
-                    float g8[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float fac = -fast_exp(f[e]);       // wkv7_cuda.cu:66
-                        f[e] = fast_exp(fac);                    // :67
-                        g8[e] = f[e] * fac;                      // :107  dw scale
-                    }
-                    float4* d2 = reinterpret_cast<float4*>(&lin[step][8][seg * 8]);
-                    d2[0] = make_float4(g8[0], g8[1], g8[2], g8[3]);
-                    d2[1] = make_float4(g8[4], g8[5], g8[6], g8[7]);
-                }
-                float4* dst = reinterpret_cast<float4*>(&lin[step][vec][seg * 8]);
-                dst[0] = make_float4(f[0], f[1], f[2], f[3]);
-                dst[1] = make_float4(f[4], f[5], f[6], f[7]);
-            }
-        }
-        if (tid < FSEG) {
-            const int step = tid >> 4, seg = tid & 15;
-            *reinterpret_cast<float4*>(&lin[step][7][seg * 4]) = presa;
-        }
-    };
-
-    const int nsc = T / SC;
-    issue((nsc - 1) * SC);
-    park();
-    block_sync();
-
-    for (int sc = nsc - 1; sc >= 0; --sc) {
-        if (sc > 0) issue((sc - 1) * SC);
-
-#pragma unroll 1
-        for (int s = SC - 1; s >= 0; --s) {
-            const int t = sc * SC + s;
-            const float* L = &lin[s][0][0];
-            auto ld4 = [&](int vec, int off, float* o) {
-                const float4 x = *reinterpret_cast<const float4*>(L + vec * N + off);
-                o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = x.w;
-            };
-            float wv[4], qv[4], kv[4], zv[4], av[4], vv[4], dyv[4], sav[4];
-            ld4(0, col0, wv); ld4(1, col0, qv); ld4(2, col0, kv); ld4(4, col0, zv); ld4(5, col0, av);
-            ld4(3, row0, vv); ld4(6, row0, dyv); ld4(7, row0, sav);
-
-            if ((t + 1) % CHUNK == 0) {
-                const float* src = p.s + (((size_t)blockIdx.x * (T / CHUNK) + t / CHUNK) * N) * N + row0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 x = *reinterpret_cast<const float4*>(src + (size_t)(col0 + j) * N);
-                    S[0][j] = x.x; S[1][j] = x.y; S[2][j] = x.z; S[3][j] = x.w;
-                }
-            }
-            float pdq[4], pdw[4], pdk[4], pda[4], pdz[4], dvv[4], dsa[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float x = 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x = fmaf(S[r][j], dyv[r], x);
-                pdq[j] = x;                                           // dq_j = sum_i S_t[i][j] dy_i
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float iw = fast_rcp(wv[j]);
-                float xw = 0.f, xk = 0.f, xa = 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float sp = (S[r][j] - kv[j] * vv[r] - av[j] * sav[r]) * iw;   // S_{t-1}
-                    S[r][j] = sp;
-                    const float d = fmaf(dyv[r], qv[j], dS[r][j]);                      // dS_t
-                    dS[r][j] = d;
-                    xw = fmaf(d, sp, xw);
-                    xk = fmaf(d, vv[r], xk);
-                    xa = fmaf(d, sav[r], xa);
-                }
-                pdw[j] = xw; pdk[j] = xk; pda[j] = xa;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float xv = 0.f, xs = 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { xv = fmaf(dS[r][j], kv[j], xv); xs = fmaf(dS[r][j], av[j], xs); }
-                dvv[r] = group_sum<4>(xv);                            // dv_i  = sum_j dS[i][j] k_j
-                dsa[r] = group_sum<4>(xs);                            // dsa_i = sum_j dS[i][j] a_j
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float x = 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    x = fmaf(S[r][j], dsa[r], x);                     // dz_j = sum_i S_{t-1}[i][j] dsa_i
-                    dS[r][j] = fmaf(dS[r][j], wv[j], dsa[r] * zv[j]); // dS_{t-1}
-                }
-                pdz[j] = x;
-            }
-            // sum the column partials over the wave's 4 row groups (lane bits 4,5)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                pdw[j] += lane_xor16(pdw[j]); pdw[j] += lane_xor32(pdw[j]);
-                pdq[j] += lane_xor16(pdq[j]); pdq[j] += lane_xor32(pdq[j]);
-                pdk[j] += lane_xor16(pdk[j]); pdk[j] += lane_xor32(pdk[j]);
-                pda[j] += lane_xor16(pda[j]); pda[j] += lane_xor32(pda[j]);
-                pdz[j] += lane_xor16(pdz[j]); pdz[j] += lane_xor32(pdz[j]);
-            }
-            if (rg == 0) {
-                *reinterpret_cast<float4*>(&part[s][0][wave][col0]) = make_float4(pdw[0], pdw[1], pdw[2], pdw[3]);
-                *reinterpret_cast<float4*>(&part[s][1][wave][col0]) = make_float4(pdq[0], pdq[1], pdq[2], pdq[3]);
-                *reinterpret_cast<float4*>(&part[s][2][wave][col0]) = make_float4(pdk[0], pdk[1], pdk[2], pdk[3]);
-                *reinterpret_cast<float4*>(&part[s][3][wave][col0]) = make_float4(pda[0], pda[1], pda[2], pda[3]);
-                *reinterpret_cast<float4*>(&part[s][4][wave][col0]) = make_float4(pdz[0], pdz[1], pdz[2], pdz[3]);
-            }
-            if (cg == 0) {
-                const size_t o = head_base + (size_t)t * tstride + row0;
-                *reinterpret_cast<uint2*>(p.dv + o) = make_uint2(pack_bf16x2(dvv[0], dvv[1]), pack_bf16x2(dvv[2], dvv[3]));
-            }
-        }
-        block_sync();
-        // cross-wave sum of the column outputs of this sub-chunk -> global (bf16)
-        {
-            constexpr int ITEMS = SC * NOUT * 32;          // (step, out, column pair)
-#pragma unroll
-            for (int i = 0; i < ITEMS / NT; ++i) {
-                const int it = i * NT + tid;
-                const int c2 = it & 31, so = it >> 5, out = so % NOUT, step = so / NOUT;
-                const float2 p0 = *reinterpret_cast<const float2*>(&part[step][out][0][2 * c2]);
-                const float2 p1 = *reinterpret_cast<const float2*>(&part[step][out][1][2 * c2]);
-                const float2 p2 = *reinterpret_cast<const float2*>(&part[step][out][2][2 * c2]);
-                const float2 p3 = *reinterpret_cast<const float2*>(&part[step][out][3][2 * c2]);
-                float x0 = (p0.x + p1.x) + (p2.x + p3.x), x1 = (p0.y + p1.y) + (p2.y + p3.y);
-                if (out == 0) { x0 *= lin[step][8][2 * c2]; x1 *= lin[step][8][2 * c2 + 1]; }
-                uint16_t* dst = out == 0 ? p.dw : out == 1 ? p.dq : out == 2 ? p.dk : out == 3 ? p.da : p.dz;
-                *reinterpret_cast<uint32_t*>(dst + head_base + (size_t)(sc * SC + step) * tstride + 2 * c2) = pack_bf16x2(x0, x1);
-            }
-        }
-        block_sync();
-        if (sc > 0) park();
-        block_sync();
-    }
-}
 
 }  // namespace wkv7
