@@ -1,12 +1,15 @@
 #!/bin/bash
 # Round evidence, run on the GPU box from the repo root:  bash benchmarks/collect_profiles.sh <tag>
-TAG=${1:-r1}; R=$PWD; O=$R/gpurun_out/$TAG; mkdir -p $O
+TAG=${1:-r2}; R=$PWD; O=$R/gpurun_out/$TAG; mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/pytest_gpu.txt
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 >> $O/pytest_gpu.txt
 timeout 600 python bench.py --steps 5 --warmup 2 2>&1 | grep -v amdgpu.ids | tail -1 > $O/bench.json
 cd /tmp; export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/step -o step -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/step.log 2>&1
+# matrix-core utilisation per kernel of the same step (counters in their own pass: no --stats, no other trace domain)
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $O/step_pmc -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-grad-cp-companion --fast-init > $O/step_pmc.log 2>&1
 cd $R
+python benchmarks/mfma_util.py $O/step_pmc > $O/step_mfma_util.json 2>&1; rm -rf $O/step_pmc
 PMC_MERGE=1 bash benchmarks/wkv7_pmc.sh 16 gpurun_out/$TAG/pmc_b16 -1 > $O/wkv7_pmc_b16.txt 2>&1
 PMC_MERGE=1 bash benchmarks/wkv7_pmc.sh 8 gpurun_out/$TAG/pmc_b8 -1 > $O/wkv7_pmc_b8.txt 2>&1
 cp profiles/wkv7_pmc.json $O/wkv7_pmc.json
@@ -23,4 +26,7 @@ python benchmarks/decode_profile.py $O/decprof/dec_results.db 4000 > $O/decode_k
 python benchmarks/prefill_micro.py 2>&1 | grep -v amdgpu > $O/prefill_micro.jsonl
 python benchmarks/wkv6_micro.py 2>&1 | grep -v amdgpu > $O/wkv6_micro.jsonl
 python benchmarks/wgrad_micro.py 2>&1 | grep -v amdgpu > $O/wgrad_micro.jsonl
+python benchmarks/tpar_micro.py 2>&1 | grep -v amdgpu > $O/tpar_micro.jsonl
+python benchmarks/attention_micro.py 2>&1 | grep -v amdgpu > $O/attention_micro.jsonl
+bash benchmarks/attention_pmc.sh gpurun_out/$TAG/attn_pmc > $O/attention_pmc.txt 2>&1
 cat $O/pytest_gpu.txt; cut -c1-600 $O/bench.json; cat $O/decode_micro.jsonl

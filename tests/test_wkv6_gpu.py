@@ -59,7 +59,7 @@ def test_reference_recurrence_fixture():
     B, T, H, N = g["B"], g["T"], g["H"], g["N"]
     f = lambda x: x.view(B, T, H, N).bfloat16()
     c = g["zero_state"]
-    y, (gr, gk, gv, gw, gu) = _run(f(g["r"]), f(g["k"]), f(g["v"]), g["w"].view(B, T, H, N).float(), g["u"].bfloat16(), f(c["gy"]))
+    y, (gr, gk, gv, gw, gu) = _run(f(g["r"]), f(g["k"]), f(g["v"]), f(g["w"]), g["u"].bfloat16(), f(c["gy"]))
     assert rel_rms(y.double(), c["y"]) < 6e-3
     for a, n in ((gr, "gr"), (gk, "gk"), (gv, "gv"), (gw, "gw")):
         assert rel_rms(a.double().reshape(c[n].shape), c[n]) < 8e-3, n
