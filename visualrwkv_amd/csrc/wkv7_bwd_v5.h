@@ -301,7 +301,7 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
         // ================================================================== producers (one chunk ahead; loads only)
         const int pw = wave - 4;
         // static priority for the producers (the younger half of the workgroup loses VALU arbitration otherwise): -7 % kernel time
-        if (MODE & 8) wave_priority<3>(); else if (MODE & 4) wave_priority<2>(); else wave_priority<1>();
+        if (MODE & 16) wave_priority<0>(); else if (MODE & 8) wave_priority<3>(); else if (MODE & 4) wave_priority<2>(); else wave_priority<1>();
         const LaneAddr la = lane_addr(c16, g, pw);
         const unsigned lane_off = (unsigned)c16 * ts + 16u * pw + 4u * g;
         auto fetch = [&](RawB& r, int c) {
@@ -334,19 +334,25 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
             KeepB keep;
             BufV5& Bn = lds.b[(c - 1) & 1];
             WKV_STAMP(0)
+            if (MODE & 128) wave_priority<0>();         // segment 1: the producers have slack, the consumers do not
             if (more) prep_a(Bn, raw, c16, 16 * pw + 4 * g, la, keep);
             vmem_drain();                               // the S0 image of chunk c-1 (issued a segment ago) has landed
             WKV_STAMP(1)
             block_sync_lds();                           // X: dR(c) is in LDS
+            if ((MODE & 128) && !(MODE & 256) && !(MODE & 4096)) { if (MODE & 2048) wave_priority<1>(); else wave_priority<(MODE & 4) ? 2 : 1>(); }
             WKV_STAMP(2)
             if (more) {
                 prep_b(Bn, raw, la, keep);
                 if (c - 1 > c_lo) fetch(raw, c - 2);    // consumed in the next iteration's first segment
             }
             WKV_STAMP(3)
+            if (MODE & 4096) wave_priority<2>();        // second half of segment 2
             dscores(lds, lds.b[c & 1], pw, c16, g, la);
             WKV_STAMP(4)
             block_sync_lds();                           // Y: dM(c) ready, all images of c-1 written
+            if (MODE & 256) wave_priority<(MODE & 4) ? 2 : 1>();
+            if (MODE & 2048) wave_priority<2>();
+            if ((MODE & 1024) && pw > 0) wave_priority<0>();
             WKV_STAMP(5)
             if (more) scores<(MODE & 2) != 0>(Bn, pw, c16, g, la);
             if (pw > 0 && c - 1 > c_lo)                 // S0 of chunk c-2 = s[c-3] into the buffer the consumers have just left
@@ -360,6 +366,7 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
     }
 
     // ====================================================================== consumers (stores only inside the loop)
+    if (MODE & 64) wave_priority<2>(); else if (MODE & 32) wave_priority<1>();
     const LaneAddr la = lane_addr(c16, g, wave);
     const int j = 16 * wave + c16;                      // key column of the j-split tiles
     f32x4 dS1[4], dS2[4];
@@ -392,6 +399,7 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
         const BufV5& B = lds.b[c & 1];
         const size_t cbase = head_base + (size_t)c * L * ts;
         WKV_STAMP(0)
+        if (MODE & 512) wave_priority<1>();
         // ---------------------------------------------------------------- segment 1: i-split (i = 16w + c16)
         {
             bf16x8 sh[2], sl[2];
@@ -456,6 +464,7 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
         }
         WKV_STAMP(1)
         block_sync_lds();                                   // X
+        if (MODE & 512) wave_priority<0>();
         WKV_STAMP(2)
         // ---------------------------------------------------------------- segment 2: j-split (j = 16w + c16)
         f32x4 dZt, dQt, dAh, dKh;
