@@ -230,7 +230,8 @@ int vrwkv_attention_relpos_fwd_bf16(int B, int S, int H, int D, const void* q, c
  *   out[b, prefix + m, n] = sum_{c,py,px} pixels[b, c, gy P + py, gx P + px] w[n, (c P + py) P + px] + bias[n] + pos[m, n]
  * pixels (B,3,Himg,Wimg) bf16; w_padded (N, KP) bf16 = the conv weight flattened to (N, 3 P P) and zero-padded to
  * KP = vrwkv_patch_embed_kp(P) columns; bias (N) / pos (M, N) bf16 or NULL; out (B, tokens_per_image, N) bf16, rows
- * < prefix of each image are left untouched (class / register tokens).  P in {14, 16}; (Himg/P)(Wimg/P) % 64 == 0. */
+ * < prefix of each image are left untouched (class / register tokens).  P in {14, 16}; (Himg/P)(Wimg/P) % 64 == 0;
+ * N % 32 == 0. */
 int vrwkv_patch_embed_bf16(int B, int Himg, int Wimg, int P, int N, const void* pixels, const void* w_padded,
                            const void* bias, const void* pos, void* out, int tokens_per_image, int prefix, void* stream);
 int vrwkv_patch_embed_kp(int P);

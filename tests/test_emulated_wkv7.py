@@ -97,7 +97,7 @@ def test_attention_forward(emu_lib, D, L, qt, S):
     assert rel_rms(o.float(), ref) < 1e-2
 
 
-@pytest.mark.parametrize("patch,side,N,prefix", [(14, 112, 32, 5), (16, 128, 48, 0)])
+@pytest.mark.parametrize("patch,side,N,prefix", [(14, 112, 32, 5), (16, 128, 64, 0)])
 def test_patch_embed(emu_lib, patch, side, N, prefix):
     """Implicit-GEMM patch embedding (csrc/patch_embed_kernels.h) vs conv2d + bias + position embedding in fp32."""
     B = 2

@@ -23,6 +23,11 @@
 #include <stdint.h>
 #include "../../include/visualrwkv_hip.h"
 #include <gfx950_prims.h>
+// 16-byte register pieces as the compiler's NATIVE vector type: private arrays of HIP's uint4 (a struct of unions) are not
+// promoted to registers and ended up in scratch memory (32 B/lane in the LayerNorm prologues of this file).
+typedef uint32_t vrwkv_u4 __attribute__((ext_vector_type(4)));
+#define uint4 vrwkv_u4
+#define make_uint4(a_, b_, c_, d_) (vrwkv_u4{(uint32_t)(a_), (uint32_t)(b_), (uint32_t)(c_), (uint32_t)(d_)})
 
 namespace {
 

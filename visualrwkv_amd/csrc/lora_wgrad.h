@@ -36,8 +36,9 @@ DEVFN bf16x8 mk8(uint2 lo, uint2 hi) {
     u32x4 v = {lo.x, lo.y, hi.x, hi.y};
     return __builtin_bit_cast(bf16x8, v);
 }
-DEVFN uint4 ld16(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
-DEVFN void st16(uint16_t* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
+// staged pieces are the NATIVE vector type: arrays of HIP's uint4 struct were kept in scratch memory by the compiler
+DEVFN u32x4 ld16(const uint16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
+DEVFN void st16(uint16_t* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
 
 template <int ND>
 __global__ __launch_bounds__(256, (ND <= 6 ? 3 : 2)) void wgrad_kernel(Args p) {       // 3 (2) workgroups per CU: register cap
@@ -53,8 +54,8 @@ __global__ __launch_bounds__(256, (ND <= 6 ? 3 : 2)) void wgrad_kernel(Args p) {
     const long nsteps = (p.M + KS - 1) / KS;
     const long t0 = nsteps * blockIdx.y / gridDim.y, t1 = nsteps * (blockIdx.y + 1) / gridDim.y;
 
-    struct Stage { uint4 w[2]; uint4 n[NL]; };
-    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+    struct Stage { u32x4 w[2]; u32x4 n[NL]; };
+    const u32x4 zero = {0u, 0u, 0u, 0u};
     auto fetch = [&](Stage& s, long t) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {

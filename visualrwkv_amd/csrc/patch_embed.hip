@@ -24,7 +24,7 @@ extern "C" int vrwkv_patch_embed_bf16(int B, int Himg, int Wimg, int P, int N, c
                                       void* stream) {
     if (B <= 0 || !pixels || !w_padded || !out || prefix < 0) return VRWKV_EINVAL;
     if (P != 14 && P != 16) return VRWKV_ESHAPE;
-    if (Himg % P || Wimg % P || N % 16) return VRWKV_ESHAPE;
+    if (Himg % P || Wimg % P || N % 32) return VRWKV_ESHAPE;
     const int gh = Himg / P, gw = Wimg / P, M = gh * gw;
     if (M % 64 || tokens_per_image < prefix + M) return VRWKV_ESHAPE;
     if ((reinterpret_cast<uintptr_t>(pixels) & 3u) || (reinterpret_cast<uintptr_t>(w_padded) & 15u) ||

@@ -603,7 +603,7 @@ _PATCH_SIZES = (14, 16)
 
 
 def patch_embed_supported(x, patch, dim):
-    if not (visual_supported(x) and x.dim() == 4 and x.shape[1] == 3 and patch in _PATCH_SIZES and dim % 16 == 0):
+    if not (visual_supported(x) and x.dim() == 4 and x.shape[1] == 3 and patch in _PATCH_SIZES and dim % 32 == 0):
         return False
     H, W = x.shape[-2:]
     return H % patch == 0 and W % patch == 0 and ((H // patch) * (W // patch)) % 64 == 0
