@@ -93,6 +93,37 @@ class _LoraMM(torch.autograd.Function):
 lora_mm = _LoraMM.apply
 LORA_WGRAD = os.environ.get("VRWKV_LORA_WGRAD", "1") != "0"      # A/B switch for benchmarks: 0 = autograd's torch.mm
 GRAD_ALIAS = os.environ.get("VRWKV_GRAD_ALIAS", "1") != "0"      # A/B switch: 0 = autograd sums the gradients of x_v, k2, v2
+DGRAD_TN = os.environ.get("VRWKV_DGRAD_TN", "1") != "0"          # A/B switch: 0 = autograd's dy.mm(W) for the input gradient of Linear
+
+
+class _LinearTN(torch.autograd.Function):
+    """F.linear(x, W) whose input gradient is issued in the layout of the forward GEMMs.  Autograd computes dx = dy.mm(W)
+    with W (N_out, K_in) row-major: the contraction index is the strided one of W (hipBLASLt "N,N"), 8-15 % slower on
+    MI355X than the "T,N" kernels the forward gets (both operands contraction-contiguous; measured 908 vs 1229 TFLOP/s at
+    41 984 x 2048 x 2048, benchmarks/dgrad_layout_micro.py).  Here dx = F.linear(dy, W^T) on a transposed copy of the
+    weight (31-77 us per weight, included in the measurement): the same T,N kernels as the forward.  dW as autograd."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return F.linear(x, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = F.linear(dy, w.t().contiguous())
+        if ctx.needs_input_grad[1]:
+            dw = dy.reshape(-1, dy.shape[-1]).t().mm(x.reshape(-1, x.shape[-1]))
+        return dx, dw
+
+
+def linear(module, x):
+    """module(x) for a bias-free nn.Linear; in training on the GPU through _LinearTN."""
+    if DGRAD_TN and module.bias is None and x.is_cuda and torch.is_grad_enabled() and x.requires_grad:
+        return _LinearTN.apply(x, module.weight)
+    return module(x)
 
 
 class _Mix(torch.autograd.Function):
@@ -434,10 +465,10 @@ def tmix_forward(m, x, v_first):
         xr, xw, xk, xv, xa, xg = mix(x, m.x_r, m.x_w, m.x_k, m.x_v, m.x_a, m.x_g)
         xv_b = xv
     mm = lora_mm if torch.is_grad_enabled() and LORA_WGRAD else torch.matmul     # training: skinny weight-gradient kernel in the backward
-    r = m.receptance(xr)
+    r = linear(m.receptance, xr)
     w = decay(mm(torch.tanh(mm(xw, m.w1)), m.w2), m.w0)
-    k = m.key(xk)
-    v = m.value(xv)
+    k = linear(m.key, xk)
+    v = linear(m.value, xv)
     al = mm(mm(xa, m.a1), m.a2)
     g = mm(torch.sigmoid(mm(xg, m.g1)), m.g2)
     if m.layer_id == 0:
@@ -452,7 +483,7 @@ def tmix_forward(m, x, v_first):
             k2_b, v2_b = k2, v2
     y = RUN_CUDA_RWKV7g(r, w, k2, v2, z, b)
     y = post(y, r, k2_b, v2_b, g, m.ln_x.weight, m.ln_x.bias, m.r_k, m.ln_x.eps)
-    return m.output(y), v_first
+    return linear(m.output, y), v_first
 
 
 def mix_prev(x, x_prev, *mus):
@@ -504,7 +535,7 @@ def cmix_forward_stateful(m, x, state):
 def cmix_forward(m, x):
     """RWKV_CMix_x070.forward (src/model.py:221-227)."""
     (k,) = mix(x, m.x_k)
-    return m.value(relu_sq(m.key(k)))
+    return linear(m.value, relu_sq(linear(m.key, k)))
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -311,7 +311,11 @@ class RWKV(nn.Module):
 
     def forward(self, x):
         x, num_tokens_to_pad = self.forward_features(x)
-        x = self.head(x)
+        if x.is_cuda and getattr(self.args, "fused", False):
+            from . import fused
+            x = fused.linear(self.head, x)              # input gradient in the forward GEMMs' layout
+        else:
+            x = self.head(x)
         return self.unpad(x, num_tokens_to_pad)
 
     @torch.no_grad()
