@@ -164,6 +164,9 @@ def main():
     ap.add_argument("--fused", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grad-cp-companion", action="store_true")
+    ap.add_argument("--profile-ops", type=str, default="",
+                    help="debugging aid: run one extra step under torch.profiler and write the GPU-time table of aten ops "
+                         "with input shapes to this file")
     ap.add_argument("--fast-init", action="store_true",
                     help="profiling runs only: normal instead of orthogonal initialisers (rocprofv3 counter collection "
                          "segfaults inside the ~30 k tiny rocsolver kernels of the QR-based initialiser)")
@@ -222,6 +225,14 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
+    if a.profile_ops and rank == 0:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+            step()
+            torch.cuda.synchronize()
+        with open(a.profile_ops, "w") as f:
+            f.write(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=400, max_name_column_width=50,
+                                                                       max_shapes_column_width=90))
     wkv7.EVENT_LOG = [] if rank == 0 else None
     t0 = time.perf_counter()
     for _ in range(a.steps):

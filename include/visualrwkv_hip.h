@@ -295,6 +295,11 @@ int vrwkv_wgrad_skinny_bf16(long M, int Nw, int D, const void* wide, const void*
  * against.  Moves 2 * bytes of HBM traffic. */
 int vrwkv_stream_copy(const void* src, void* dst, long bytes, void* stream);
 
+/* out[c][r] = in[r][c] for a row-major (rows, cols) bf16 matrix (rows, cols multiples of 64): the transposed weight copy
+ * that lets a Linear's input gradient run in the forward GEMMs' operand layout (replaces the strided torch copy inside
+ * autograd's mm; fused.linear). */
+int vrwkv_transpose_bf16(long rows, long cols, const void* in, void* out, void* stream);
+
 /* Hardware probe for the GPU tests (MFMA lane maps, cross-lane primitives); one wave.
  * which: 0 = 16x16x4 f32, 1 = 32x32x2 f32, 2 = 16x16x32 bf16, 3 = 32x32x16 bf16 (d = a*b, row-major
  * f32 operands), 4 = cross-lane primitives (a: 64 floats, d: 896 floats). */

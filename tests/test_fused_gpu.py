@@ -304,3 +304,25 @@ def test_aliased_outputs_sum_gradients_in_the_kernels():
     got = kgrads(outs)
     for a, b in zip(got, ref):
         assert float((a.float() - b.float()).abs().max()) <= 0.02 * float(b.float().abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize("rows,cols", [(2048, 2048), (8192, 2048), (2048, 65536), (64, 192)])
+def test_transpose_kernel_is_exact(rows, cols):
+    from visualrwkv_amd import fused
+    w = torch.randn(rows, cols, device="cuda").bfloat16()
+    assert torch.equal(fused.transpose2d(w), w.t().contiguous())
+
+
+def test_linear_tn_matches_autograd():
+    """fused.linear: same outputs and gradients as nn.Linear's autograd (the input gradient only changes its GEMM layout)."""
+    from visualrwkv_amd import fused
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(256, 512, bias=False).cuda().bfloat16()
+    x = torch.randn(4, 64, 256, device="cuda").bfloat16().requires_grad_(True)
+    gy = torch.randn(4, 64, 512, device="cuda").bfloat16()
+    y = fused.linear(lin, x); y.backward(gy)
+    gx, gw = x.grad.clone(), lin.weight.grad.clone()
+    x.grad = None; lin.weight.grad = None
+    y2 = lin(x); y2.backward(gy)
+    assert torch.equal(y, y2)
+    assert rel_rms(gx.float(), x.grad.float()) < 2e-3 and rel_rms(gw.float(), lin.weight.grad.float()) < 2e-3
