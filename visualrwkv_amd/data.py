@@ -133,3 +133,155 @@ def multi_image_collate_fn(batch: Sequence[Dict]) -> Dict:
     images["num_image_per_sample"] = [len(x["images"]["dino"]) for x in with_img]
     return dict(input_text=[x["input_text"] for x in batch], input_ids=torch.stack([x["input_ids"] for x in batch]),
                 labels=torch.stack([x["labels"] for x in batch]), images=images, sample_id=[str(x["sample_id"]) for x in batch])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Dataset, loader and device prefetcher (VisualRWKV-v7/v7.00/src/dataset.py:167-246, train.py:219-222)
+#
+# The reference decodes AND transforms every image (three bicubic resizes, one to 1024 x 1024) in its single DataLoader
+# worker.  Here the workers only decode (PIL -> uint8 HWC); the three tower transforms run on the GPU
+# (visualrwkv_amd.image.process_images) on a side stream, one batch ahead of the training step, together with the
+# host-to-device copies from pinned memory.  Sampling, templating, masking and collation are the reference's.
+# ---------------------------------------------------------------------------------------------------------------
+class MyDataset(torch.utils.data.Dataset):
+    """dataset.py:167-246.  `args` needs: data_file, image_folder, tokenizer, ctx_len, num_token_per_image, epoch_steps,
+    real_bsz, micro_bsz (the reference's names).  `global_rank`, `world_size` and `real_epoch` are attributes the trainer
+    sets, as in the reference (train_callback).  decode_only=True (default) returns the decoded uint8 images under
+    'images_u8' for the device transform; decode_only=False applies `image_processor` (a callable image -> dict of
+    (3,S,S) tensors, as args.image_processor of the reference) in the worker."""
+
+    def __init__(self, args, decode_only: bool = True, image_processor=None):
+        import json
+        from .dp import largest_3n_plus_2_prime
+        self.args = args
+        self.tokenizer = args.tokenizer
+        with open(args.data_file, "r") as f:
+            self.list_data_dict = json.load(f)
+        self.list_data_dict_reverse = list(reversed(self.list_data_dict))
+        self.data_size = len(self.list_data_dict)
+        self.magic_prime = largest_3n_plus_2_prime(self.data_size)
+        self.samples_per_epoch = args.epoch_steps * args.real_bsz
+        self.decode_only = decode_only
+        self.image_processor = image_processor
+        self.global_rank, self.world_size, self.real_epoch = 0, 1, 0
+
+    def __len__(self):
+        return self.args.epoch_steps * self.args.micro_bsz
+
+    def record(self, idx: int) -> Dict:
+        from .dp import rank_strided_sample
+        i, rev = rank_strided_sample(self.real_epoch, idx, self.global_rank, self.world_size, self.samples_per_epoch, self.magic_prime)
+        return (self.list_data_dict_reverse if rev else self.list_data_dict)[i]
+
+    def __getitem__(self, idx):
+        import os
+        sample = copy.deepcopy(self.record(idx))
+        images_u8, pixel_values = None, None
+        if "image" in sample:
+            names = [sample["image"]] if isinstance(sample["image"], str) else list(sample["image"])
+            sample["image"] = names
+            try:
+                from PIL import Image
+                import numpy as np
+                decoded = [Image.open(os.path.join(self.args.image_folder, n)).convert("RGB") for n in names]
+                if self.decode_only:
+                    images_u8 = [torch.from_numpy(np.asarray(im).copy()) for im in decoded]           # (H,W,3) uint8
+                else:
+                    per = [self.image_processor(im) for im in decoded]
+                    pixel_values = {k: torch.stack([p[k] for p in per], dim=0) for k in per[0]}
+            except Exception:                                    # unreadable image: zero tensors, as the reference (dataset.py:213-215)
+                images_u8, pixel_values = None, None
+        out = build_sample(sample, self.tokenizer, self.args.ctx_len, self.args.num_token_per_image, pixel_values)
+        if "image" in sample and self.decode_only:
+            if images_u8 is not None:
+                del out["images"]
+                out["images_u8"] = images_u8
+            else:
+                out["images_missing"] = len(sample["image"])
+        return out
+
+
+def decode_collate_fn(batch: Sequence[Dict]) -> Dict:
+    """Collation for decode-only samples: ids / labels stacked as in multi_image_collate_fn, decoded images kept as a flat
+    list of uint8 (H,W,3) tensors (sizes differ) with the per-sample counts; samples whose images could not be read carry
+    their count in 'missing' (zero tensors after the transform, as the reference)."""
+    imgs, counts = [], []
+    for x in batch:
+        if "images_u8" in x:
+            imgs.extend(x["images_u8"]); counts.append(len(x["images_u8"]))
+        elif "images" in x or "images_missing" in x:
+            n = x.get("images_missing", len(x["images"]["dino"]) if "images" in x else 0)
+            imgs.extend([None] * n); counts.append(n)
+    return dict(input_text=[x["input_text"] for x in batch], input_ids=torch.stack([x["input_ids"] for x in batch]),
+                labels=torch.stack([x["labels"] for x in batch]), images_u8=imgs, num_image_per_sample=counts,
+                sample_id=[str(x["sample_id"]) for x in batch])
+
+
+def make_loader(dataset: "MyDataset", micro_bsz: int, num_workers: int = 4):
+    """train.py:219-222 with decode-only workers: shuffle=False (the dataset does the rank-strided sampling), drop_last,
+    pinned memory; more than the reference's single worker is safe because __getitem__ depends on idx only."""
+    return torch.utils.data.DataLoader(dataset, collate_fn=decode_collate_fn if dataset.decode_only else multi_image_collate_fn,
+                                       shuffle=False, pin_memory=torch.cuda.is_available(), batch_size=micro_bsz,
+                                       num_workers=num_workers, persistent_workers=False, drop_last=True)
+
+
+class DevicePrefetcher:
+    """Iterates a loader one batch ahead: host-to-device copies and the three tower transforms of batch i+1 are issued on a
+    side stream while the training step of batch i runs; `next()` makes the current stream wait for them.  Yields the
+    `samples` dict VisualRWKV.forward takes (input_ids, labels, images{dino,siglip,sam,num_image_per_sample}, sample_id)."""
+
+    def __init__(self, loader, device, towers=("dino", "siglip", "sam"), dtype=torch.bfloat16):
+        self.loader, self.device, self.towers, self.dtype = loader, torch.device(device), tuple(towers), dtype
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+
+    def _to_device(self, batch):
+        from .image import TOWER_SPECS, process_images
+        nb = self.device.type == "cuda"
+        out = {"input_ids": batch["input_ids"].to(self.device, non_blocking=nb), "labels": batch["labels"].to(self.device, non_blocking=nb),
+               "sample_id": batch["sample_id"], "input_text": batch.get("input_text")}
+        if "images_u8" in batch:
+            if batch["images_u8"]:
+                per_tower = {t: [] for t in self.towers}
+                for im in batch["images_u8"]:
+                    if im is None:
+                        for t in self.towers:
+                            per_tower[t].append(torch.zeros(1, 3, TOWER_SPECS[t][0], TOWER_SPECS[t][0], dtype=self.dtype, device=self.device))
+                    else:
+                        im = im.pin_memory() if nb and not im.is_pinned() else im
+                        px = process_images([im.to(self.device, non_blocking=nb)], self.towers, self.dtype)
+                        for t in self.towers:
+                            per_tower[t].append(px[t])
+                images = {t: torch.cat(v, dim=0) for t, v in per_tower.items()}
+                images["num_image_per_sample"] = batch["num_image_per_sample"]
+                out["images"] = images
+        elif "images" in batch:
+            out["images"] = {k: (v.to(self.device, dtype=self.dtype, non_blocking=nb) if torch.is_tensor(v) else v)
+                             for k, v in batch["images"].items()}
+        return out
+
+    def __iter__(self):
+        it = iter(self.loader)
+
+        def produce():
+            try:
+                host = next(it)
+            except StopIteration:
+                return None
+            if self.stream is None:
+                return self._to_device(host), None
+            with torch.cuda.stream(self.stream):
+                dev = self._to_device(host)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+            return dev, ev
+
+        nxt = produce()
+        while nxt is not None:
+            cur, ev = nxt
+            nxt = produce()                                   # batch i+1 is in flight while the caller trains on batch i
+            if ev is not None:
+                torch.cuda.current_stream(self.device).wait_event(ev)
+                for v in list(cur.values()) + list(cur.get("images", {}).values()):
+                    if torch.is_tensor(v):
+                        v.record_stream(torch.cuda.current_stream(self.device))
+            yield cur
