@@ -30,5 +30,6 @@ python benchmarks/tpar_micro.py 2>&1 | grep -v amdgpu > $O/tpar_micro.jsonl
 python benchmarks/attention_micro.py 2>&1 | grep -v amdgpu > $O/attention_micro.jsonl
 python benchmarks/patch_embed_micro.py 2>&1 | grep -v amdgpu > $O/patch_embed_micro.jsonl
 python benchmarks/dgrad_layout_micro.py 2>&1 | grep -v amdgpu > $O/dgrad_layout_micro.jsonl
+python benchmarks/image_micro.py 2>&1 | grep -v amdgpu > $O/image_micro.jsonl
 bash benchmarks/attention_pmc.sh gpurun_out/$TAG/attn_pmc > $O/attention_pmc.txt 2>&1
 cat $O/pytest_gpu.txt; cut -c1-600 $O/bench.json; cat $O/decode_micro.jsonl

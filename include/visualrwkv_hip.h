@@ -235,6 +235,12 @@ int vrwkv_attention_relpos_fwd_bf16(int B, int S, int H, int D, const void* q, c
 int vrwkv_patch_embed_bf16(int B, int Himg, int Wimg, int P, int N, const void* pixels, const void* w_padded,
                            const void* bias, const void* pos, void* out, int tokens_per_image, int prefix, void* stream);
 int vrwkv_patch_embed_kp(int P);
+/* Tower image transform on the device: antialiased bicubic resize of one decoded (H,W,3) uint8 image to
+ * S x S, clip to [0,255], normalise ((v/255 - mean)/std), planar (3,S,S) bf16 or fp32 output (replaces, per image and tower,
+ * Resize((S,S), bicubic) + ToTensor + Normalize run by the reference's DataLoader worker: src/vision.py:96-121).
+ * mean3 / std3: host pointers to 3 floats. */
+int vrwkv_resize_normalize_u8(int H, int W, const void* src_hwc_u8, int S, const float* mean3, const float* std3,
+                              void* dst_chw, int dst_is_f32, void* stream);
 /* Test hook: query tiles of 16 per wave in the attention kernels (1 or 2; 0 = default = 2). */
 int vrwkv_attention_set_qtiles(int qt);
 

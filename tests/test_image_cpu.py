@@ -29,3 +29,37 @@ def test_process_images_shapes_and_dtype():
     assert out["dino"].shape == (2, 3, 448, 448) and out["siglip"].shape == (2, 3, 448, 448) and out["sam"].shape == (2, 3, 1024, 1024)
     assert all(v.dtype == torch.bfloat16 for v in out.values())
     assert float(out["siglip"].float().abs().max()) <= 1.0 + 1e-2
+
+
+@pytest.mark.parametrize("hw,size", [((37, 53), 64), ((300, 200), 64), ((64, 64), 64), ((20, 31), 96)])
+def test_hip_resize_kernel_on_the_emulator(hw, size):
+    """csrc/image_kernels.h (window / weight tables / accumulation) run on the host emulator against the torch statement
+    (F.interpolate bicubic antialias + clip + normalise): down-sampling, up-sampling, identity, mixed."""
+    import ctypes
+
+    from tests.emu.build import build_emu
+    from visualrwkv_amd import image
+    lib = ctypes.CDLL(build_emu())
+    g = torch.Generator().manual_seed(hw[0])
+    img = torch.randint(0, 256, (*hw, 3), dtype=torch.uint8, generator=g)
+    out = torch.zeros(3, size, size)
+    m3, s3 = (ctypes.c_float * 3)(*image.IMAGENET_MEAN), (ctypes.c_float * 3)(*image.IMAGENET_STD)
+    assert lib.emu_resize_normalize_u8(hw[0], hw[1], ctypes.c_void_p(img.data_ptr()), size, m3, s3, ctypes.c_void_p(out.data_ptr()), 1) == 0
+    ref = image.resize_normalize(img, size, image.IMAGENET_MEAN, image.IMAGENET_STD)[0]
+    assert (out - ref).abs().max() < 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw", [(480, 640), (1365, 2048), (100, 75), (448, 448)])
+def test_hip_resize_kernel_on_the_gpu(hw):
+    """The HIP transform against the torch statement evaluated on the CPU, for the three towers, fp32 and bf16 outputs."""
+    from visualrwkv_amd import image
+    g = torch.Generator().manual_seed(hw[1])
+    img = torch.randint(0, 256, (*hw, 3), dtype=torch.uint8, generator=g)
+    for t, (size, mean, std) in image.TOWER_SPECS.items():
+        ref = image.resize_normalize(img, size, mean, std)                  # CPU: F.interpolate path
+        out = image.resize_normalize(img.cuda(), size, mean, std)           # GPU: HIP kernel
+        assert out.is_cuda and out.shape == ref.shape
+        assert (out.cpu() - ref).abs().max() < 5e-4, t
+        ob = image.resize_normalize(img.cuda(), size, mean, std, dtype=torch.bfloat16)
+        assert ob.dtype == torch.bfloat16 and (ob.float().cpu() - ref).abs().max() < 2e-2

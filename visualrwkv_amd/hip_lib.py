@@ -68,6 +68,8 @@ PROTOTYPES = {
     "vrwkv_wgrad_skinny_bf16": (_c_int, [_c_long, _c_int, _c_int] + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 2),
     "vrwkv_stream_copy":(_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p]),
     "vrwkv_transpose_bf16": (_c_int, [_c_long, _c_long, _c_void_p, _c_void_p, _c_void_p]),
+    "vrwkv_resize_normalize_u8": (_c_int, [_c_int, _c_int, _c_void_p, _c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
+                                           _c_void_p, _c_int, _c_void_p]),
     "vrwkv_debug_probe": (_c_int, [_c_int] + [_c_void_p] * 4),
 }
 

@@ -19,9 +19,27 @@ TOWER_SPECS = {"dino": (448, IMAGENET_MEAN, IMAGENET_STD), "siglip": (448, SIGLI
                "sam": (1024, IMAGENET_MEAN, IMAGENET_STD)}                       # SAM reuses the DINOv2 transform (vision.py:114-119)
 
 
+def _hip_resize_normalize(img_u8: torch.Tensor, size: int, mean, std, dtype) -> torch.Tensor:
+    """One (H,W,3) uint8 CUDA image through vrwkv_resize_normalize_u8 (csrc/image_kernels.h)."""
+    import ctypes
+    from . import hip_lib
+    img = img_u8.contiguous()
+    H, W, _ = img.shape
+    out = torch.empty(1, 3, size, size, dtype=dtype, device=img.device)
+    m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    rc = hip_lib.load().vrwkv_resize_normalize_u8(H, W, img.data_ptr(), size, m3, s3, out.data_ptr(), int(dtype == torch.float32),
+                                                  hip_lib.launch_stream(img.device))
+    hip_lib.check(rc, "vrwkv_resize_normalize_u8")
+    return out
+
+
 def resize_normalize(img_u8: torch.Tensor, size: int, mean: Sequence[float], std: Sequence[float],
                      dtype: torch.dtype = torch.float32) -> torch.Tensor:
-    """img_u8: (H,W,3) or (N,H,W,3) uint8 -> (N,3,size,size) normalised.  The aspect ratio is not kept (Resize((S,S)))."""
+    """img_u8: (H,W,3) or (N,H,W,3) uint8 -> (N,3,size,size) normalised.  The aspect ratio is not kept (Resize((S,S))).
+    On the GPU: one HIP kernel per image (resample + clip + normalise + layout); elsewhere the same arithmetic in torch."""
+    if img_u8.is_cuda and img_u8.dtype == torch.uint8 and dtype in (torch.float32, torch.bfloat16):
+        imgs = [img_u8] if img_u8.dim() == 3 else list(img_u8)
+        return torch.cat([_hip_resize_normalize(im, size, mean, std, dtype) for im in imgs], dim=0)
     x = img_u8 if img_u8.dim() == 4 else img_u8.unsqueeze(0)
     x = x.permute(0, 3, 1, 2).float()
     x = F.interpolate(x, size=(size, size), mode="bicubic", align_corners=False, antialias=True)
