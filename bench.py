@@ -33,13 +33,13 @@ FWD_B, BWD_B = 34, 46          # algorithmic bytes per bf16 element at chunk len
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md
 
 
-def build_args(name, ctx_len, n_img_tokens, towers, grad_cp, fused):
+def build_args(name, ctx_len, n_img_tokens, towers, grad_cp, fused, vit_minibatch=4):
     m = MODELS[name]
     return SimpleNamespace(n_layer=m["n_layer"], n_embd=m["n_embd"], dim_att=m["n_embd"], head_size_a=64,
                            head_size_divisor=8, vocab_size=65536, dropout=0, grad_cp=grad_cp, ctx_len=ctx_len,
                            load_model="", num_token_per_image=n_img_tokens, proj_type="mlp", vision_towers=towers,
                            vision_image_size=448, vision_tower_kwargs=None, weight_decay=0.0, fused=fused,
-                           check_image_tokens=False)
+                           check_image_tokens=False, vit_minibatch=vit_minibatch)
 
 
 def synthetic_batch(B, ctx_len, n_img, towers, device, seed):
@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--towers", default="dino,siglip")
     ap.add_argument("--grad-cp", type=int, default=0)
     ap.add_argument("--fused", type=int, default=1)
+    ap.add_argument("--vit-minibatch", type=int, default=16, help="images per ViT forward (the reference's loop uses 4 to save memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grad-cp-companion", action="store_true")
     ap.add_argument("--profile-ops", type=str, default="",
@@ -194,7 +195,7 @@ def main():
     from visualrwkv_amd.dp import Zero1Engine
     from visualrwkv_amd.visual import VisualRWKV
     towers = tuple(t for t in a.towers.split(",") if t)
-    args = build_args(a.model, a.ctx_len, a.img_tokens, towers, a.grad_cp, bool(a.fused))
+    args = build_args(a.model, a.ctx_len, a.img_tokens, towers, a.grad_cp, bool(a.fused), a.vit_minibatch)
     torch.manual_seed(42)
     if a.fast_init:
         torch.nn.init.orthogonal_ = lambda t, gain=1.0: t.normal_(0, 0.02 * gain)
