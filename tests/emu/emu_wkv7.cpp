@@ -40,7 +40,7 @@ int emu_wkv7_backward_chunked(int B, int T, int H, const void* w, const void* q,
     static_assert(sizeof(wkv7v5::LdsV5) <= 160 * 1024, "LDS budget");
     const dim3 grid((unsigned)(B * H));
     if (mode == 2) { emu::launch(grid, dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 2>(p); }); return (int)sizeof(wkv7c::LdsB3); }
-    if (mode == 6) { emu::launch(grid, dim3(512), [&] { wkv7v5::bwd_kernel_v5<false, 6 + 128 + 512>(p); }); return (int)sizeof(wkv7v5::LdsV5); }
+    if (mode == 6) { emu::launch(grid, dim3(512), [&] { wkv7v5::bwd_kernel_v5<false, 2 + 4 + 128>(p); }); return (int)sizeof(wkv7v5::LdsV5); }
     return -1;
 }
 
@@ -82,7 +82,7 @@ extern "C" int emu_wkv7_backward_segments_v5(int B, int T, int H, int nseg, cons
                     (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
                     (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
     p.ds_in = ds_in; p.ds_out = ds_out; p.nseg = nseg;
-    emu::launch(dim3((unsigned)(B * H * nseg)), dim3(512), [&] { wkv7v5::bwd_kernel_v5<false, 6 + 128 + 512, true>(p); });
+    emu::launch(dim3((unsigned)(B * H * nseg)), dim3(512), [&] { wkv7v5::bwd_kernel_v5<false, 2 + 4 + 128, true>(p); });
     return 0;
 }
 

@@ -277,7 +277,10 @@ DEVFN void tiles_op(const f32x4* tl, bf16x8* oh, bf16x8* ol) {
 }
 
 // ------------------------------------------------------------------------------------------ kernel
-// MODE bit 1: T doubling on the bf16 matrix core (split operands) instead of the f32 one.
+// MODE bit 1 (2): T doubling on the bf16 matrix core (split operands) instead of the f32 one.
+// MODE bit 2 (4): producers at wave priority 2 instead of 1.
+// MODE bit 7 (128): priorities by segment -- in segment 1 the producers drop to 0 and the consumers rise to 1 (the producers
+// have ~1.2k cycles of slack per chunk there and the consumers none); everywhere else the producers stay above the consumers.
 // TPAR: sequence-parallel launch (see wkv7_bwd_v3.h): blockIdx.x = (b*H + h) * nseg + seg, chunks [c_lo, c_hi),
 // dL/dS enters as ds_in[b,h,seg] and leaves as ds_out[b,h,seg] (both [i][j] fp32).
 template <bool PROF, int MODE = 0, bool TPAR = false>
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
         // ================================================================== producers (one chunk ahead; loads only)
         const int pw = wave - 4;
         // static priority for the producers (the younger half of the workgroup loses VALU arbitration otherwise): -7 % kernel time
-        if (MODE & 16) wave_priority<0>(); else if (MODE & 8) wave_priority<3>(); else if (MODE & 4) wave_priority<2>(); else wave_priority<1>();
+        wave_priority<(MODE & 4) ? 2 : 1>();
         const LaneAddr la = lane_addr(c16, g, pw);
         const unsigned lane_off = (unsigned)c16 * ts + 16u * pw + 4u * g;
         auto fetch = [&](RawB& r, int c) {
@@ -339,20 +342,16 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
             vmem_drain();                               // the S0 image of chunk c-1 (issued a segment ago) has landed
             WKV_STAMP(1)
             block_sync_lds();                           // X: dR(c) is in LDS
-            if ((MODE & 128) && !(MODE & 256) && !(MODE & 4096)) { if (MODE & 2048) wave_priority<1>(); else wave_priority<(MODE & 4) ? 2 : 1>(); }
+            if (MODE & 128) wave_priority<(MODE & 4) ? 2 : 1>();
             WKV_STAMP(2)
             if (more) {
                 prep_b(Bn, raw, la, keep);
                 if (c - 1 > c_lo) fetch(raw, c - 2);    // consumed in the next iteration's first segment
             }
             WKV_STAMP(3)
-            if (MODE & 4096) wave_priority<2>();        // second half of segment 2
             dscores(lds, lds.b[c & 1], pw, c16, g, la);
             WKV_STAMP(4)
             block_sync_lds();                           // Y: dM(c) ready, all images of c-1 written
-            if (MODE & 256) wave_priority<(MODE & 4) ? 2 : 1>();
-            if (MODE & 2048) wave_priority<2>();
-            if ((MODE & 1024) && pw > 0) wave_priority<0>();
             WKV_STAMP(5)
             if (more) scores<(MODE & 2) != 0>(Bn, pw, c16, g, la);
             if (pw > 0 && c - 1 > c_lo)                 // S0 of chunk c-2 = s[c-3] into the buffer the consumers have just left
@@ -366,7 +365,6 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
     }
 
     // ====================================================================== consumers (stores only inside the loop)
-    if (MODE & 64) wave_priority<2>(); else if (MODE & 32) wave_priority<1>();
     const LaneAddr la = lane_addr(c16, g, wave);
     const int j = 16 * wave + c16;                      // key column of the j-split tiles
     f32x4 dS1[4], dS2[4];
@@ -399,7 +397,7 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
         const BufV5& B = lds.b[c & 1];
         const size_t cbase = head_base + (size_t)c * L * ts;
         WKV_STAMP(0)
-        if (MODE & 512) wave_priority<1>();
+        if (MODE & 128) wave_priority<1>();
         // ---------------------------------------------------------------- segment 1: i-split (i = 16w + c16)
         {
             bf16x8 sh[2], sl[2];
@@ -464,7 +462,7 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
         }
         WKV_STAMP(1)
         block_sync_lds();                                   // X
-        if (MODE & 512) wave_priority<0>();
+        if (MODE & 128) wave_priority<0>();
         WKV_STAMP(2)
         // ---------------------------------------------------------------- segment 2: j-split (j = 16w + c16)
         f32x4 dZt, dQt, dAh, dKh;

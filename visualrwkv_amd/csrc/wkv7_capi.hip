@@ -15,8 +15,8 @@ namespace {
 int g_fwd_variant = -1;
 int g_bwd_variant = -1;
 // T chain on the bf16 matrix core (2) + producer priority 2 (4; same-box A/B: 1.18 -> 1.09 ms) + priorities swapped in
-// segment 1, where the producers have ~1.2k cycles of slack per chunk and the consumers none (128 + 512; 1.09 -> 1.04 ms)
-constexpr int BWD_V5_MODE = 6 + 128 + 512;
+// segment 1, where the producers have ~1.2k cycles of slack per chunk and the consumers none (128; 1.09 -> 1.04 ms)
+constexpr int BWD_V5_MODE = 2 + 4 + 128;
 constexpr int BWD_V3_MODE = 2;    // same-process A/B on MI355X (benchmarks/wkv7_ab.py): counters +1..3 % slower, bf16x3 doubling -1 %
 
 inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
