@@ -49,12 +49,16 @@ def test_c_oracle_matches_torch_restatement(B, T, H):
     w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=7 + T)
     y, s, sa = wkv7_c.forward(w, q, k, v, z, a)
     yr, sr, sar = wkv7_forward_ref(w, q, k, v, z, a)
-    assert rel_rms(y.float(), yr) < 2e-4
-    assert rel_rms(s, sr) < 1e-5 and rel_rms(sa, sar) < 1e-5
+    # what the two restatements of the same fp32 algorithm actually give (C: expf / -O2 contraction, torch: exp + eager ops):
+    # the fp32 by-products agree to 1e-6, the bf16 outputs are bit-equal except for round-to-nearest flips
+    assert rel_rms(y.float(), yr) < 2e-4 and (y.float() != yr.float()).float().mean() < 2e-3
+    assert rel_rms(s, sr) < 5e-7 and rel_rms(sa, sar) < 1e-6
     outs = wkv7_c.backward(w, q, k, v, z, a, dy, s, sa)
     outs_r = wkv7_backward_ref(w, q, k, v, z, a, dy, sr, sar)
     for name, o, r in zip(["dw", "dq", "dk", "dv", "dz", "da"], outs, outs_r):
         assert rel_rms(o.float(), r) < 5e-4, name
+        flips = (o.float() != r.float()).float().mean()
+        assert flips < (0.10 if name in ("dw", "dz") else 0.01), (name, float(flips))     # dw / dz pass through exp(-exp(w)) and 1/w
 
 
 def test_fp32_restatement_vs_fp64_truth_structured_inputs():

@@ -150,3 +150,33 @@ def test_towers_use_the_patch_embed_kernel(monkeypatch):
     assert len(calls) == 2
     assert rel_rms(a_v.float(), b_v.float()) < 1e-2
     assert rel_rms(a_s.float(), b_s.float()) < 1e-2
+
+
+def test_sam_vit_b_full_size_product_path(monkeypatch):
+    """cfg 5's SAM tower at its real size (1024^2 input, 64 x 64 grid, 14 x 14 windows, global attention over 4096 tokens,
+    12 blocks) through the product path -- patch-embed kernel, rel-pos attention kernel for both window sizes -- against
+    the eager statement of the same module (torch permute + linear, SDPA with the materialised bias) on the same weights."""
+    from visualrwkv_amd import attention as att, fused, hip_attention
+    from visualrwkv_amd.vit import SamImageEncoder
+    torch.manual_seed(0)
+    m = SamImageEncoder().cuda().bfloat16()
+    with torch.no_grad():
+        for n, p_ in m.named_parameters():
+            if "rel_pos" in n:
+                p_.normal_(0, 0.2)                       # zero-initialised in the reference: make the bias path live
+            p_.requires_grad_(False)
+    x = torch.randn(1, 3, 1024, 1024, device="cuda").bfloat16()
+    sides = []
+    orig = hip_attention.flash_forward_relpos
+    monkeypatch.setattr(hip_attention, "flash_forward_relpos", lambda q, k, v, rh, rw, side: (sides.append(side), orig(q, k, v, rh, rw, side))[1])
+    with torch.no_grad():
+        a = m(x)
+        assert sides.count(64) == 4 and sides.count(14) == 8          # 4 global + 8 windowed blocks ran the HIP kernel
+        att.set_hip_attention(False)
+        monkeypatch.setattr(fused, "patch_embed_supported", lambda *a_, **k_: False)
+        try:
+            b = m(x)
+        finally:
+            att.set_hip_attention(True)
+    assert a.shape == (1, 1024, 32, 32) and torch.isfinite(a.float()).all()     # (B, 4 x 256 channels, 32, 32) after the 2x2 space-to-depth
+    assert rel_rms(a.float(), b.float()) < 2e-2
