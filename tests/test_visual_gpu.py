@@ -180,3 +180,78 @@ def test_sam_vit_b_full_size_product_path(monkeypatch):
             att.set_hip_attention(True)
     assert a.shape == (1, 1024, 32, 32) and torch.isfinite(a.float()).all()     # (B, 4 x 256 channels, 32, 32) after the 2x2 space-to-depth
     assert rel_rms(a.float(), b.float()) < 2e-2
+
+
+def _siglip_pair(tr, hidden, heads, inter, image, depth=3):
+    from visualrwkv_amd.vit import TimmViT
+    cfg = tr.SiglipVisionConfig(hidden_size=hidden, intermediate_size=inter, num_hidden_layers=depth, num_attention_heads=heads,
+                                image_size=image, patch_size=14, hidden_act="gelu_pytorch_tanh", layer_norm_eps=1e-6)
+    hf = tr.SiglipVisionModel(cfg).eval()
+    mine = TimmViT(img_size=image, patch=14, dim=hidden, depth=depth, heads=heads, mlp_hidden=inter, class_token=False, reg_tokens=0,
+                   ls_init=None, act="gelu_tanh").eval()
+    v = hf.vision_model if hasattr(hf, "vision_model") else hf
+    with torch.no_grad():
+        mine.patch_embed.proj.weight.copy_(v.embeddings.patch_embedding.weight)
+        mine.patch_embed.proj.bias.copy_(v.embeddings.patch_embedding.bias)
+        mine.pos_embed.copy_(v.embeddings.position_embedding.weight[None])
+        for b, hb in zip(mine.blocks, v.encoder.layers):
+            b.norm1.load_state_dict(hb.layer_norm1.state_dict()); b.norm2.load_state_dict(hb.layer_norm2.state_dict())
+            b.attn.qkv.weight.copy_(torch.cat([hb.self_attn.q_proj.weight, hb.self_attn.k_proj.weight, hb.self_attn.v_proj.weight]))
+            b.attn.qkv.bias.copy_(torch.cat([hb.self_attn.q_proj.bias, hb.self_attn.k_proj.bias, hb.self_attn.v_proj.bias]))
+            b.attn.proj.load_state_dict(hb.self_attn.out_proj.state_dict())
+            b.mlp.fc1.load_state_dict(hb.mlp.fc1.state_dict()); b.mlp.fc2.load_state_dict(hb.mlp.fc2.state_dict())
+    return hf, mine
+
+
+def _dinov2_pair(tr, hidden, heads, image, depth=3):
+    from visualrwkv_amd.vit import TimmViT
+    cfg = tr.Dinov2WithRegistersConfig(hidden_size=hidden, num_hidden_layers=depth, num_attention_heads=heads, image_size=image,
+                                       patch_size=14, num_register_tokens=4, mlp_ratio=4, layerscale_value=0.3, layer_norm_eps=1e-6)
+    hf = tr.Dinov2WithRegistersModel(cfg).eval()
+    mine = TimmViT(img_size=image, patch=14, dim=hidden, depth=depth, heads=heads, mlp_hidden=4 * hidden, class_token=True, reg_tokens=4,
+                   ls_init=0.3, act="gelu").eval()
+    e = hf.embeddings
+    with torch.no_grad():
+        e.cls_token.normal_(); e.register_tokens.normal_(); e.position_embeddings.normal_(std=0.1)
+        e.position_embeddings[:, 0].zero_()
+        mine.patch_embed.proj.load_state_dict(e.patch_embeddings.projection.state_dict())
+        mine.pos_embed.copy_(e.position_embeddings[:, 1:])
+        mine.cls_token.copy_(e.cls_token); mine.reg_token.copy_(e.register_tokens)
+        for b, hb in zip(mine.blocks, hf.encoder.layer):
+            a = hb.attention.attention
+            b.norm1.load_state_dict(hb.norm1.state_dict()); b.norm2.load_state_dict(hb.norm2.state_dict())
+            b.attn.qkv.weight.copy_(torch.cat([a.query.weight, a.key.weight, a.value.weight]))
+            b.attn.qkv.bias.copy_(torch.cat([a.query.bias, a.key.bias, a.value.bias]))
+            b.attn.proj.load_state_dict(hb.attention.output.dense.state_dict())
+            b.mlp.fc1.load_state_dict(hb.mlp.fc1.state_dict()); b.mlp.fc2.load_state_dict(hb.mlp.fc2.state_dict())
+            b.ls1.gamma.copy_(hb.layer_scale1.lambda1); b.ls2.gamma.copy_(hb.layer_scale2.lambda1)
+    return hf, mine
+
+
+@pytest.mark.parametrize("tower", ["siglip", "dinov2"])
+def test_timm_style_towers_on_the_gpu_against_transformers(tower, monkeypatch):
+    """Not a self-comparison: the GPU product path of the two timm-style towers (patch-embed kernel, flash attention with
+    head dims 72 / 64, 448^2 input = 1024 patches) against the architecturally equivalent `transformers` module evaluated
+    in fp32 on the CPU with the same weights (the pin SURVEY.md 8c prescribes for the un-vendored timm)."""
+    tr = pytest.importorskip("transformers")
+    if tower == "dinov2" and not hasattr(tr, "Dinov2WithRegistersModel"):
+        pytest.skip("transformers without Dinov2WithRegisters")
+    from visualrwkv_amd import fused, hip_attention
+    torch.manual_seed(3)
+    hf, mine = _siglip_pair(tr, 288, 4, 512, 448) if tower == "siglip" else _dinov2_pair(tr, 128, 2, 448)
+    x = torch.randn(2, 3, 448, 448).bfloat16().float()
+    with torch.no_grad():
+        hs = hf(pixel_values=x, output_hidden_states=True).hidden_states[2]
+        ref = hs if tower == "siglip" else hs[:, 5:]
+    calls = {"pe": 0, "fa": 0}
+    pe, fa = fused.patch_embed, hip_attention.flash_forward
+    monkeypatch.setattr(fused, "patch_embed", lambda *a, **k: (calls.__setitem__("pe", calls["pe"] + 1), pe(*a, **k))[1])
+    monkeypatch.setattr(hip_attention, "flash_forward", lambda *a, **k: (calls.__setitem__("fa", calls["fa"] + 1), fa(*a, **k))[1])
+    m = mine.cuda().bfloat16()
+    for p_ in m.parameters():
+        p_.requires_grad_(False)
+    with torch.no_grad():
+        got = m(x.cuda().bfloat16())
+    assert calls["pe"] == 1 and calls["fa"] == 2                     # the HIP kernels are what ran (2 blocks up to depth-2)
+    assert got.shape == ref.shape
+    assert rel_rms(got.float().cpu(), ref) < 2e-2                    # bf16 weights and activations vs fp32
