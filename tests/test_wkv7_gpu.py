@@ -270,3 +270,49 @@ def test_tparallel_training_op_equals_default(monkeypatch):
     sa0 = torch.empty(B, T, H, 64, dtype=torch.float32, device="cuda")
     torch.ops.wind_backstepping.forward(w, q, k, v, z, a, y0, s0, sa0)
     assert rel_rms(s, s0) < 2e-4 and rel_rms(sa, sa0) < 2e-4 and rel_rms(y.float(), y0.float()) < 4e-3
+
+
+def test_random_shapes_and_input_scales_against_oracle(hip_lib, dev):
+    """A seeded sweep of ragged shapes (B, H not powers of two, T from one chunk to 25 chunks) and of input regimes the
+    fixed cases do not reach: the strongest decays the operator's domain allows (RWKV-7 feeds w_raw = -softplus(.) - 0.5
+    <= -0.5, i.e. w_t >= 0.545; the reference backward un-steps the state by dividing by w_t, src wkv7_cuda.cu:84-100, and
+    is only defined there), very weak decays, large-magnitude activations.  Forward outputs, both by-products and all six gradients against the C oracle."""
+    import random
+    rng = random.Random(20260926)
+    cases = [(rng.randint(1, 5), 16 * rng.randint(1, 25), rng.randint(1, 7)) for _ in range(8)]
+    for n, (B, T, H) in enumerate(cases):
+        w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=1000 + n)
+        if n % 3 == 1:                       # strong decays
+            w = torch.empty_like(w, dtype=torch.float32).uniform_(-0.6, -0.5, generator=torch.Generator().manual_seed(n)).bfloat16()
+        if n % 3 == 2:                       # weak decays, larger activations
+            w = (w.float() - 4.0).bfloat16()
+            q, v = (q.float() * 3).bfloat16(), (v.float() * 3).bfloat16()
+        yr, sr, sar = wkv7_c.forward(w, q, k, v, z, a)
+        ref = wkv7_c.backward(w, q, k, v, z, a, dy, sr, sar)
+        y, s, sa = _capi_forward(hip_lib, *[x.to(dev) for x in (w, q, k, v, z, a)])
+        outs = _capi_backward(hip_lib, *[x.to(dev) for x in (w, q, k, v, z, a, dy, sr, sar)])
+        torch.cuda.synchronize()
+        assert rel_rms(y.float().cpu(), yr.float()) < TOL, (B, T, H)
+        assert rel_rms(s.cpu(), sr) < 2e-5 and rel_rms(sa.cpu(), sar) < 2e-5, (B, T, H)
+        for name, o, r in zip(NAMES, outs, ref):
+            assert torch.isfinite(o.float()).all(), (name, B, T, H)
+            assert rel_rms(o.float().cpu(), r.float()) < TOL, (name, B, T, H, n % 3)
+
+
+def test_outside_the_reference_domain_the_chunked_kernels_stay_accurate(hip_lib, dev):
+    """Decays stronger than RWKV-7 ever feeds (w_raw up to +1, w_t down to 0.066: the cumulative decay over a 16-token chunk
+    reaches 1e-19).  The reference backward un-steps the state by dividing by w_t and loses all accuracy there (so does
+    its literal restatement, the oracle); the chunked closed form does not un-step: forward and all six gradients stay
+    within the bf16 bar of fp64 autograd through the naive recurrence."""
+    from oracle.wkv7_oracle import wkv7_autograd
+    B, T, H = 1, 64, 2
+    w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=77)
+    w = torch.empty_like(w, dtype=torch.float32).uniform_(-0.5, 1.0, generator=torch.Generator().manual_seed(5)).bfloat16()
+    yt, gt = wkv7_autograd(w, q, k, v, z, a, dy)
+    y, s, sa = _capi_forward(hip_lib, *[x.to(dev) for x in (w, q, k, v, z, a)])
+    outs = _capi_backward(hip_lib, *[x.to(dev) for x in (w, q, k, v, z, a, dy)], s, sa)
+    torch.cuda.synchronize()
+    assert rel_rms(y.float().cpu().double(), yt) < 4e-3
+    for name, o, r in zip(NAMES, outs, gt):
+        assert torch.isfinite(o.float()).all(), name
+        assert rel_rms(o.float().cpu().double(), r) < 6e-3, name
