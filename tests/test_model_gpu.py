@@ -167,3 +167,17 @@ def test_full_visual_step_matches_an_independent_fp32_cpu_evaluation(monkeypatch
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
     assert all(e < 4e-2 for e in errs.values()), worst       # observed: worst 2.1e-2 (a token-shift mix parameter); bf16 path vs fp32
     assert checked >= 30
+    # ---- one optimizer step on both sides (CPU: torch AdamW + clip_grad_norm_; GPU: ZeRO-1 engine, HIP AdamW with the clip
+    # factor formed on the device), then the loss again
+    train = [p for p in ref.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(train, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0)
+    torch.nn.utils.clip_grad_norm_(train, 1.0)
+    opt.step()
+    eng.step(1e-3)
+    with monkeypatch.context() as mp, torch.no_grad():
+        mp.setattr(rwkv7, "RUN_CUDA_RWKV7g", run_cpu)
+        loss_ref2 = ref.training_step({"input_ids": ids, "labels": labels, "sample_id": ["0", "1"], "images": {k: v.float() for k, v in imgs.items()}})
+    with torch.no_grad():
+        loss2 = m.training_step(batch)
+    assert float(loss_ref2) < float(loss_ref) and float(loss2) < float(loss)
+    assert abs(float(loss2) - float(loss_ref2)) < 1.5e-2 * abs(float(loss_ref2)), (float(loss2), float(loss_ref2))
