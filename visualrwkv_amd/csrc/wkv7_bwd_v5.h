@@ -282,7 +282,9 @@ DEVFN void tiles_op(const f32x4* tl, bf16x8* oh, bf16x8* ol) {
 // MODE bit 7 (128): priorities by segment -- in segment 1 the producers drop to 0 and the consumers rise to 1 (the producers
 // have ~1.2k cycles of slack per chunk there and the consumers none); everywhere else the producers stay above the consumers.
 // TPAR: sequence-parallel launch (see wkv7_bwd_v3.h): blockIdx.x = (b*H + h) * nseg + seg, chunks [c_lo, c_hi),
-// dL/dS enters as ds_in[b,h,seg] and leaves as ds_out[b,h,seg] (both [i][j] fp32).
+// dL/dS enters as ds_in[b,h,seg] and leaves as ds_out[b,h,seg] (both [i][j] fp32).  A launch that only asks for ds_out
+// (ds_in == null: the first pass of the sequence-parallel backward, whose gradients are discarded) runs LITE: only what
+// propagates dL/dS is computed -- no S0 images, no score gradients, no dV, no j-split output products, no tail, no stores.
 template <bool PROF, int MODE = 0, bool TPAR = false>
 __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
     LdsV5& lds = *reinterpret_cast<LdsV5*>(dyn_lds());
@@ -298,6 +300,7 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
     const int c_lo = TPAR ? (int)((long)nchunk * seg / nseg) : 0, c_hi = TPAR ? (int)((long)nchunk * (seg + 1) / nseg) : nchunk;
     const size_t head_base = ((size_t)(bh / H) * T * H + (bh % H)) * N;
     const float* sbase = p.s + (size_t)bh * nchunk * N * N;
+    const bool lite = TPAR && p.ds_out != nullptr && p.ds_in == nullptr;        // wave-uniform; constant false without TPAR
     WKV_STAMP_DECL
 
     if (wave >= 4) {
@@ -319,13 +322,13 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
         {   // prologue: the last chunk, completely
             KeepB keep;
             BufV5& B = lds.b[(c_hi - 1) & 1];
-            dma_state(B.s0, c_hi - 1 > 0 ? sbase + (size_t)(c_hi - 2) * N * N : nullptr, 4 * pw, 4 * pw + 4, lane);   // S0 of chunk c is s[c-1]
+            if (!lite) dma_state(B.s0, c_hi - 1 > 0 ? sbase + (size_t)(c_hi - 2) * N * N : nullptr, 4 * pw, 4 * pw + 4, lane);   // S0 of chunk c is s[c-1]
             prep_a(B, raw, c16, 16 * pw + 4 * g, la, keep);
             prep_b(B, raw, la, keep);
             if (c_hi - 1 > c_lo) fetch(raw, c_hi - 2);
             block_sync_lds();
-            scores<(MODE & 2) != 0>(B, pw, c16, g, la);
-            if (pw > 0 && c_hi - 1 > c_lo)
+            if (!lite || pw < 2) scores<(MODE & 2) != 0>(B, pw, c16, g, la);       // lite: only T and M_qa are used
+            if (!lite && pw > 0 && c_hi - 1 > c_lo)
                 dma_state(lds.b[(c_hi - 2) & 1].s0, c_hi - 2 > 0 ? sbase + (size_t)(c_hi - 3) * N * N : nullptr, pw == 1 ? 0 : pw == 2 ? 5 : 10, pw == 1 ? 5 : pw == 2 ? 10 : 16, lane);
             block_sync_lds();
         }
@@ -349,12 +352,12 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
                 if (c - 1 > c_lo) fetch(raw, c - 2);    // consumed in the next iteration's first segment
             }
             WKV_STAMP(3)
-            dscores(lds, lds.b[c & 1], pw, c16, g, la);
+            if (!lite) dscores(lds, lds.b[c & 1], pw, c16, g, la);
             WKV_STAMP(4)
             block_sync_lds();                           // Y: dM(c) ready, all images of c-1 written
             WKV_STAMP(5)
-            if (more) scores<(MODE & 2) != 0>(Bn, pw, c16, g, la);
-            if (pw > 0 && c - 1 > c_lo)                 // S0 of chunk c-2 = s[c-3] into the buffer the consumers have just left
+            if (more && (!lite || pw < 2)) scores<(MODE & 2) != 0>(Bn, pw, c16, g, la);
+            if (!lite && pw > 0 && c - 1 > c_lo)                 // S0 of chunk c-2 = s[c-3] into the buffer the consumers have just left
                 dma_state(lds.b[c & 1].s0, c - 2 > 0 ? sbase + (size_t)(c - 3) * N * N : nullptr, pw == 1 ? 0 : pw == 2 ? 5 : 10, pw == 1 ? 5 : pw == 2 ? 10 : 16, lane);
             WKV_STAMP(6)
             block_sync_lds();                           // Z
@@ -430,6 +433,7 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
                 st8(&lds.dr[1][la.own], tl);
             }
             // dV^T[i][t] = sum_j dS[i][j] Kb[t][j] + sum_s dY[s][i] M_qk[s][t] + sum_s dR[s][i] M_zk[s][t]
+            if (!lite) {
             f32x4 dV = mfma32(dyd, ld16(&B.sc[1][la.hl]), zero4());
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -444,6 +448,7 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
                 dV = mfma32(rhl, ld16(&B.dz[0][la.row[1]]), dV);                 // [M_zk_l 0]
             }
             *reinterpret_cast<uint2*>(p.dv + cbase + out_off) = make_uint2(cvt_pk_bf16(dV[0], dV[1]), cvt_pk_bf16(dV[2], dV[3]));
+            }
             // dS^T <- diag(c_L) dS^T + [Qt^T | Zt^T] [dY ; dR]
             const bf16x8 y1 = mk8(dyv, rh), y2 = mk8(0u, 0u, rl.x, rl.y);
 #pragma unroll
@@ -473,11 +478,14 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib) {
                 // [ib][r] = S0[i = tix(ib, 4g+r)][j]  <-  image row j (zeros for the first chunk of the sequence)
-                const float4 x = *reinterpret_cast<const float4*>(&B.s0[f32_off(j, tix(ib, 4 * g))]);
-                S0[ib][0] = x.x; S0[ib][1] = x.y; S0[ib][2] = x.z; S0[ib][3] = x.w;
+                if (!lite) {
+                    const float4 x = *reinterpret_cast<const float4*>(&B.s0[f32_off(j, tix(ib, 4 * g))]);
+                    S0[ib][0] = x.x; S0[ib][1] = x.y; S0[ib][2] = x.z; S0[ib][3] = x.w;
+                } else S0[ib] = zero4();
                 dU[ib] = dS2[ib];
                 dU[ib][0] *= clj; dU[ib][1] *= clj; dU[ib][2] *= clj; dU[ib][3] *= clj;
             }
+            if (!lite) {
             bf16x8 s0h[2], s0l[2], duh[2], dul[2];
             tiles_op(S0, s0h, s0l);
             tiles_op(dU, duh, dul);
@@ -514,6 +522,7 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
                 dKh = mfma32(duh[1], vr, dKh);
                 dKh = mfma32(dul[1], vr, dKh);
             }
+            }
             // dS <- dU + [dY^T | dR^T] [Qt ; Zt]
             qzh = mk8(lds_read_tr16(&B.opnd[2][la.trc]), lds_read_tr16(&B.opnd[0][la.trc]));
             qzl = mk8(lds_read_tr16(&B.opnd[3][la.trc]), lds_read_tr16(&B.opnd[1][la.trc]));
@@ -542,6 +551,7 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
         block_sync_lds();                                   // Y
         WKV_STAMP(4)
         // ---------------------------------------------------------------- segment 3: dM products + element-wise tail
+        if (!lite) {
         {
             // dZt += dM_za Ah + dM_zk Kh ; dQt += dM_qa Ah + dM_qk Kh : X = [Ah^T | Kh^T], Y = pair image rows
             const bf16x8 akh = mk8(lds_read_tr16(&B.opnd[4][la.trc]), lds_read_tr16(&B.opnd[6][la.trc]));
@@ -595,6 +605,7 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
             *reinterpret_cast<uint2*>(p.dk + o) = make_uint2(cvt_pk_bf16(dk[0], dk[1]), cvt_pk_bf16(dk[2], dk[3]));
             *reinterpret_cast<uint2*>(p.dz + o) = make_uint2(cvt_pk_bf16(dz[0], dz[1]), cvt_pk_bf16(dz[2], dz[3]));
             *reinterpret_cast<uint2*>(p.da + o) = make_uint2(cvt_pk_bf16(da[0], da[1]), cvt_pk_bf16(da[2], da[3]));
+        }
         }
         WKV_STAMP(5)
         block_sync_lds();                                   // Z
