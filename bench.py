@@ -1,7 +1,13 @@
 #!/usr/bin/env python
 """Training-step benchmark of the VisualRWKV-7 hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU over RCCL.  Either the caller starts the ranks (`python -m torch.distributed.run --nproc-per-node N
+... bench.py --gpus N`, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or -- when WORLD_SIZE is not set --
+bench.py re-executes itself under torch.distributed.run with N ranks on 127.0.0.1 (the reference: `--devices 8 --strategy
+deepspeed_stage_1`, VisualRWKV-v7/v7.00/train.py:75-76,98).  `--backend gloo --model tiny` runs the same entry point on host
+cores (fp32, eager modules, the op's CPU key): the multi-rank plumbing test of tests/test_bench_cpu.py, not a benchmark.
 
 One step = ViT encode (frozen SigLIP + DINOv2) -> pool -> projector -> scatter -> RWKV-7 forward ->
 shifted CE (+L2Wrap) -> backward -> bucketed reduce-scatter -> clip 1.0 -> fused AdamW -> all-gather, on a
@@ -28,21 +34,25 @@ MODELS = {   # sizes of the RWKV-x070 checkpoints the refer
     "1b5": dict(n_layer=24, n_embd=2048),
     "0b4": dict(n_layer=24, n_embd=1024),
     "0b1": dict(n_layer=12, n_embd=768),
+    "tiny": dict(n_layer=2, n_embd=128),       # plumbing only (CPU / gloo test of the N > 1 launch path)
 }
+TINY_TOWERS = {"dino": dict(depth=2, dim=64, heads=1), "siglip": dict(depth=2, dim=64, heads=1, mlp_hidden=96),
+               "sam": dict(img_size=128, dim=64, depth=2, heads=1, out_chans=16, window=3, global_attn_indexes=(1,))}
 FWD_B, BWD_B = 34, 46          # algorithmic bytes per bf16 element at chunk length 16
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md
 
 
 def build_args(name, ctx_len, n_img_tokens, towers, grad_cp, fused, vit_minibatch=4):
     m = MODELS[name]
+    tiny = name == "tiny"
     return SimpleNamespace(n_layer=m["n_layer"], n_embd=m["n_embd"], dim_att=m["n_embd"], head_size_a=64,
                            head_size_divisor=8, vocab_size=65536, dropout=0, grad_cp=grad_cp, ctx_len=ctx_len,
                            load_model="", num_token_per_image=n_img_tokens, proj_type="mlp", vision_towers=towers,
-                           vision_image_size=448, vision_tower_kwargs=None, weight_decay=0.0, fused=fused,
-                           check_image_tokens=False, vit_minibatch=vit_minibatch)
+                           vision_image_size=56 if tiny else 448, vision_tower_kwargs=TINY_TOWERS if tiny else None,
+                           weight_decay=0.0, fused=fused, check_image_tokens=False, vit_minibatch=vit_minibatch)
 
 
-def synthetic_batch(B, ctx_len, n_img, towers, device, seed):
+def synthetic_batch(B, ctx_len, n_img, towers, device, seed, side=448, sam_side=1024, dtype=torch.bfloat16):
     """ids uniform in [0,65535) with a run of n_img image placeholders after a 4-token prefix,
     labels -100 on the first 60 %, pixels N(0,1) bf16."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -53,9 +63,53 @@ def synthetic_batch(B, ctx_len, n_img, towers, device, seed):
     labels[ids == 65535] = -100
     images = {}
     for t in towers:
-        side = 1024 if t == "sam" else 448
-        images[t] = torch.randn(B, 3, side, side, device=device, generator=g).bfloat16()
+        px = sam_side if t == "sam" else side
+        images[t] = torch.randn(B, 3, px, px, device=device, generator=g).to(dtype)
     return {"input_ids": ids, "labels": labels, "images": images, "sample_id": [str(i) for i in range(B)]}
+
+
+class ByteTokenizer:
+    """Stand-in for the RWKV world tokenizer (not shipped with the reference checkout): any object with
+    encode(str) -> list[int] serves data.MyDataset; UTF-8 bytes shifted past the special ids."""
+    def encode(self, text):
+        return [b + 300 for b in text.encode("utf-8")]
+
+
+def loader_batches(a, towers, dev, rank, world, n_files=64, n_records=512):
+    """--data loader: the reference's input pipeline end to end (train.py:219-222, src/dataset.py:167-246) on synthetic
+    files -- n_files JPEGs (640 x 480, smooth random content so that the entropy decode is photo-like) and a LLaVA-style
+    JSON on local disk -> data.MyDataset (rank-strided sampling, templating, masking; workers only decode) ->
+    data.make_loader -> data.DevicePrefetcher (H2D copies + the tower transforms on a side stream, one batch ahead).
+    Yields the `samples` dicts VisualRWKV.forward takes, forever."""
+    import json as _json
+    import tempfile
+    import numpy as np
+    from PIL import Image
+    from visualrwkv_amd import data as vdata
+    root = tempfile.mkdtemp(prefix=f"vrwkv_bench_data_r{rank}_")
+    rng = np.random.default_rng(1234 + rank)
+    for i in range(n_files):
+        low = rng.integers(0, 255, size=(15, 20, 3), dtype=np.uint8)
+        Image.fromarray(low).resize((640, 480), Image.BICUBIC).save(os.path.join(root, f"img{i:03d}.jpg"), quality=90)
+    words = ["the", "image", "shows", "a", "view", "of", "some", "objects", "near", "window", "and", "light", "table"]
+    n_text = a.ctx_len - a.img_tokens
+    recs = []
+    for i in range(n_records):
+        q = "<image>\nDescribe the picture in detail."
+        ans = " ".join(words[(i + j) % len(words)] for j in range(n_text))[: n_text + 64]      # truncated to ctx_len by preprocess
+        recs.append({"id": f"s{i}", "image": f"img{i % n_files:03d}.jpg",
+                     "conversations": [{"from": "human", "value": q}, {"from": "gpt", "value": ans}]})
+    with open(os.path.join(root, "data.json"), "w") as f:
+        _json.dump(recs, f)
+    dargs = SimpleNamespace(data_file=os.path.join(root, "data.json"), image_folder=root, tokenizer=ByteTokenizer(), ctx_len=a.ctx_len,
+                            num_token_per_image=a.img_tokens, epoch_steps=1 << 20, real_bsz=a.micro_bsz * world, micro_bsz=a.micro_bsz)
+    ds = vdata.MyDataset(dargs, decode_only=True)
+    ds.global_rank, ds.world_size, ds.real_epoch = rank, world, 0
+    loader = vdata.make_loader(ds, a.micro_bsz, num_workers=a.loader_workers)
+    for batch in vdata.DevicePrefetcher(loader, dev, towers=towers, dtype=torch.bfloat16):
+        imgs = batch.get("images", {})
+        batch["images"] = {k: v for k, v in imgs.items() if k in towers}       # tensors only (bench batches have one image each)
+        yield batch
 
 
 def stream_copy_gbps(dev, nbytes=2 << 30, iters=10):
@@ -172,30 +226,70 @@ def main():
                     help="profiling runs only: normal instead of orthogonal initialisers (rocprofv3 counter collection "
                          "segfaults inside the ~30 k tiny rocsolver kernels of the QR-based initialiser)")
     ap.add_argument("--gemm-tuning", type=int, default=1)         # library-GEMM kernel choice from the shipped TunableOp file
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI, one MI355X per rank (the benchmark); gloo = host cores, tiny model only "
+                         "(plumbing test of the multi-rank launch path)")
+    ap.add_argument("--data", default="synthetic", choices=["synthetic", "loader"],
+                    help="loader: synthetic JPEGs on disk -> data.MyDataset workers -> DevicePrefetcher (train.py:219-222)")
+    ap.add_argument("--loader-workers", type=int, default=8)
+    ap.add_argument("--async-gather", type=int, default=1, help="overlap the parameter all-gather with the next ViT encode")
     a = ap.parse_args()
+    cpu_mode = a.backend == "gloo"
+    if cpu_mode and a.model != "tiny":
+        ap.error("--backend gloo is the host-core plumbing mode: use --model tiny")
+    if a.model == "tiny":          # shapes of the tiny plumbing model unless given explicitly
+        given = {x.split("=")[0] for x in sys.argv[1:] if x.startswith("--")}
+        if "--ctx-len" not in given: a.ctx_len = 64
+        if "--img-tokens" not in given: a.img_tokens = 16
+        if "--micro-bsz" not in given: a.micro_bsz = 2
+        if "--towers" not in given: a.towers = "dino,siglip,sam"
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # nobody started the ranks: start them (one process per GPU, rendezvous on 127.0.0.1, a free port)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC (RCCL across processes on this driver)
+        os.execv(sys.executable, cmd)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if cpu_mode:
+        dev = torch.device("cpu")
+        torch.set_num_threads(max(1, (os.cpu_count() or 2) // max(world, 1) // 2))
+    else:
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (or --backend gloo --model tiny for the CPU plumbing run)"
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    ranks_seen = 1
     if world > 1 or os.environ.get("VRWKV_FORCE_COLLECTIVES") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if cpu_mode:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                       # the number of ranks the collective library actually connected
+        ranks_seen = int(ones.item())
+        assert ranks_seen == dist.get_world_size() == world, (ranks_seen, dist.get_world_size(), world)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from visualrwkv_amd import build, wkv7
     build.build()
     n_tuned = 0
-    if a.gemm_tuning:
+    if a.gemm_tuning and not cpu_mode:
         from visualrwkv_amd.gemm_tuning import enable_tuned_gemms
         n_tuned = enable_tuned_gemms()
     from visualrwkv_amd.dp import Zero1Engine
     from visualrwkv_amd.visual import VisualRWKV
     towers = tuple(t for t in a.towers.split(",") if t)
-    args = build_args(a.model, a.ctx_len, a.img_tokens, towers, a.grad_cp, bool(a.fused), a.vit_minibatch)
+    args = build_args(a.model, a.ctx_len, a.img_tokens, towers, a.grad_cp, bool(a.fused) and not cpu_mode, a.vit_minibatch)
+    dtype = torch.float32 if cpu_mode else torch.bfloat16     # host cores: BASELINE config 1's fp32 mode (the op's CPU key)
     torch.manual_seed(42)
     if a.fast_init:
         torch.nn.init.orthogonal_ = lambda t, gain=1.0: t.normal_(0, 0.02 * gain)
@@ -205,13 +299,26 @@ def main():
         for n, p in model.rwkv.named_parameters():
             if p.dim() >= 2 and float(p.abs().max()) == 0.0:
                 p.normal_(0, 0.01)
-    model = model.to(torch.bfloat16)
+    model = model.to(dtype)
     model.freeze_emb()         # fine-tune recipe: ViT and embedding frozen (train.py:196, model.py:349)
     engine = Zero1Engine(model, lr=2e-5, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0, grad_clip=1.0, bucket_mb=200.0,
-                         force_collectives=os.environ.get("VRWKV_FORCE_COLLECTIVES") == "1")
-    batch = synthetic_batch(a.micro_bsz, a.ctx_len, a.img_tokens, towers, dev, seed=1000 + rank)
+                         force_collectives=os.environ.get("VRWKV_FORCE_COLLECTIVES") == "1", async_gather=bool(a.async_gather))
+    tiny = a.model == "tiny"
+    batch = synthetic_batch(a.micro_bsz, a.ctx_len, a.img_tokens, towers, dev, seed=1000 + rank, side=56 if tiny else 448,
+                            sam_side=128 if tiny else 1024, dtype=dtype)
+
+    data_kind = "synthetic"
+    feed = None
+    if a.data == "loader":
+        assert not cpu_mode, "--data loader needs the GPU transform path"
+        feed = loader_batches(a, towers, dev, rank, world)
+        data_kind = (f"loader: synthetic 640x480 JPEGs + LLaVA-style JSON on local disk -> MyDataset ({a.loader_workers} decode workers) "
+                     "-> DevicePrefetcher (device transforms, one batch ahead)")
 
     def step():
+        nonlocal batch
+        if feed is not None:
+            batch = next(feed)
         engine.zero_grad()
         loss = model.training_step(batch)
         loss.backward()
@@ -221,7 +328,8 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not cpu_mode:
+            torch.cuda.synchronize()
 
     for _ in range(a.warmup):
         step()
@@ -230,7 +338,7 @@ def main():
         from torch.profiler import ProfilerActivity, profile
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
             step()
-            torch.cuda.synchronize()
+            fence()
         with open(a.profile_ops, "w") as f:
             f.write(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=400, max_name_column_width=50,
                                                                        max_shapes_column_width=90))
@@ -251,7 +359,7 @@ def main():
     # headline keeps all activations in the 288 GB of HBM (grad_cp=0).  Same model, same batch, two more timed steps with
     # recompute so that its cost is visible beside the headline (not part of `value`).
     cp1 = None
-    if a.grad_cp == 0 and not a.no_grad_cp_companion:
+    if a.grad_cp == 0 and not a.no_grad_cp_companion and not cpu_mode:
         args.grad_cp = 1
         step(); fence()
         t1 = time.perf_counter()
@@ -266,14 +374,15 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": f"train tokens/sec/node VisualRWKV-7 {a.model.upper()} bf16", "value": tokens / dt, "unit": "tokens/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "metric": f"train tokens/sec/node VisualRWKV-7 {a.model.upper()} {'fp32 (host cores)' if cpu_mode else 'bf16'}", "value": tokens / dt, "unit": "tokens/s",
+            "n_gpus": world, "ranks_seen_by_collective": ranks_seen, "backend": ("gloo (host cores)" if cpu_mode else "rccl") if dist.is_initialized() else "none (1 rank)",
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32" if cpu_mode else "bf16", "data": data_kind,
             "config": {"workload": f"VisualRWKV-7 {a.model} + {'+'.join(towers)} ViT, {a.img_tokens} img + {a.ctx_len - a.img_tokens} text tokens, "
                                    f"full train step (fwd+bwd+ZeRO-1 AdamW)", "model": f"VisualRWKV-7 {a.model}",
                        "global_batch": world * a.micro_bsz, "seq_len": a.ctx_len, "parallelism": f"dp{world}",
-                       "grad_cp": a.grad_cp, "fused_elementwise": bool(a.fused), "loss": float(loss.detach()),
-                       "micro_bsz": a.micro_bsz, "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+                       "grad_cp": a.grad_cp, "fused_elementwise": bool(args.fused), "loss": float(loss.detach()),
+                       "micro_bsz": a.micro_bsz, "peak_mem_GB": None if cpu_mode else round(torch.cuda.max_memory_allocated() / 2**30, 1),
                        "gemm_kernels": f"TunableOp file, {n_tuned} shapes" if n_tuned else "library default",
                        "grad_cp1_same_run": cp1},
         }
@@ -301,7 +410,7 @@ def main():
                 if rec:                                    # NOT measured in this run: the committed rocprofv3 PMC passes
                     out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = "profiles/wkv7_pmc.json (separate rocprofv3 --pmc passes of benchmarks/wkv7_pmc.sh, same shape)"
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not cpu_mode:
             out["cpu_baseline"] = cpu_baseline(args.n_embd, a.ctx_len)
         print(json.dumps(out))
     if dist.is_initialized():

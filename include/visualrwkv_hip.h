@@ -50,6 +50,16 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H,
                              void* dw, void* dq, void* dk, void* dv, void* dz, void* da,
                              void* stream);
 
+/* The same operator on the host cores -- what the `CPU` dispatch key of torch.ops.wind_backstepping runs (BASELINE config 1:
+ * fp32 CPU WKV path; cuda/wkv7_op.cpp:26 registers the CUDA key only).  Host pointers; dtype 0 = bf16 activations (the
+ * op's contract), 1 = float32 activations (RWKV_FLOAT_MODE=fp32); s / sa as above, always f32.  One task per (b, head)
+ * on n_threads host threads (<= 0: all hardware threads).  csrc/wkv7_host.hip. */
+int vrwkv_wkv7_forward_host(int B, int T, int H, int dtype, const void* w, const void* q, const void* k, const void* v,
+                            const void* z, const void* a, void* y, float* s, float* sa, int n_threads);
+int vrwkv_wkv7_backward_host(int B, int T, int H, int dtype, const void* w, const void* q, const void* k, const void* v,
+                             const void* z, const void* a, const void* dy, const float* s, const float* sa,
+                             void* dw, void* dq, void* dk, void* dv, void* dz, void* da, int n_threads);
+
 /* Sequence-parallel WKV7 backward (no counterpart in the reference): nseg workgroups per head, each
  * walks a contiguous range of 16-token chunks of the same tensors as vrwkv_wkv7_backward_bf16.  ds_in (B,H,nseg,64,64)
  * f32, [i][j]: dL/dS at the END of every range (NULL = zeros); ds_out, same shape: dL/dS at the START of the range.
@@ -262,7 +272,8 @@ int vrwkv_adaptive_pool_bf16(int B, int side_in, int side_out, int D, const void
 int vrwkv_gate_fwd_bf16(long n, const void* x, const void* g, void* out, void* stream);
 int vrwkv_gate_bwd_bf16(long n, const void* x, const void* g, const void* dout, void* dg, void* dx, void* stream);
 /* ln_v of the projector fused with the masked scatter of preparing_embedding: out[row_index[n]] = LayerNorm(x[n]) for the
- * ntok projected image tokens, written into the (rows, C) token-embedding tensor `out`; row_index: device int64.  mean /
+ * ntok projected image tokens, written into the (rows, C) token-embedding tensor `out`; row_index: device int64, distinct; a negative entry drops that
+ * feature row (fewer placeholders than features: the reference truncates, src/model.py:487-491).  mean /
  * rstd (ntok fp32 each) are saved for the backward, which reads dout[row_index[n]] and returns dx (ntok, C) and
  * dwb = (dgamma, dbeta) (2 C fp32); ws: vrwkv_add_ln_ws_floats(ntok, C) floats. */
 int vrwkv_ln_scatter_fwd_bf16(long ntok, int C, float eps, const void* x, const void* w, const void* b, const long* row_index,

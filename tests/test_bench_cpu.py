@@ -26,3 +26,22 @@ def test_synthetic_batch_schema():
     assert torch.equal(lab[:, 38:], ids[:, 38:])
     assert b["images"]["dino"].shape == (2, 3, 448, 448) and b["images"]["sam"].shape == (2, 3, 1024, 1024)
     assert b["images"]["siglip"].dtype == torch.bfloat16 and len(b["sample_id"]) == 2
+
+
+def test_bench_starts_its_own_ranks_two_gloo_ranks_on_host_cores():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: bench.py re-executes itself under
+    torch.distributed.run, both ranks join the collective, rank 0 prints the one JSON line (the tiny fp32 model through the
+    op's CPU key and the ZeRO-1 engine on gloo -- the launch path of the 8-GPU run, train.py:75-76,98)."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--model", "tiny",
+                          "--steps", "1", "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen_by_collective"] == 2 and rec["config"]["parallelism"] == "dp2"
+    assert rec["config"]["global_batch"] == 4 and rec["value"] > 0 and 5.0 < rec["config"]["loss"] < 12.5

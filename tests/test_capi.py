@@ -52,12 +52,22 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         raise AssertionError("expected HipLibraryError")
 
 
-def test_op_rejects_cpu_tensors():
+def test_op_has_a_cpu_key_and_validates_its_arguments():
+    """the op is registered for the CPU key too (BASELINE config 1); wrong dtypes / shapes are errors."""
     import pytest
     import torch
-    import visualrwkv_amd.wkv7 as wk
+    import visualrwkv_amd.wkv7 as wk  # noqa: F401
     x = torch.zeros(1, 16, 1, 64, dtype=torch.bfloat16)
     s = torch.zeros(1, 1, 1, 64, 64)
     sa = torch.zeros(1, 16, 1, 64)
-    with pytest.raises(NotImplementedError):
-        torch.ops.wind_backstepping.forward(x, x, x, x, x, x, x.clone(), s, sa)
+    y = torch.ones_like(x)
+    torch.ops.wind_backstepping.forward(x, x, x, x, x, x, y, s, sa)
+    assert float(y.abs().max()) == 0.0
+    with pytest.raises(TypeError):
+        torch.ops.wind_backstepping.forward(x.half(), x, x, x, x, x, y, s, sa)
+    with pytest.raises(TypeError):
+        torch.ops.wind_backstepping.forward(x, x.float(), x, x, x, x, y, s, sa)
+    with pytest.raises(ValueError):
+        torch.ops.wind_backstepping.forward(x[:, :8], x, x, x, x, x, y, s, sa)
+    with pytest.raises(ValueError):
+        torch.ops.wind_backstepping.forward(x, x, x, x, x, x, y, s[:, :, :, :32], sa)

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libvisualrwkv_hip.so")
 HASH_PATH = LIB_PATH + ".hash"      # content hash of the sources the library was built from; travels with it
 ARCH = "gfx950"
 
-SOURCES = ["wkv7_capi.hip", "probe.hip", "fused_ops.hip", "tmix_fused.hip", "attention.hip", "wkv7_step.hip", "ln_fused.hip", "wkv6_capi.hip", "loss_fused.hip", "gemv_decode.hip", "decode_fused.hip", "lora_wgrad.hip", "visual_ops.hip", "patch_embed.hip", "image_ops.hip"]
+SOURCES = ["wkv7_capi.hip", "wkv7_host.hip", "probe.hip", "fused_ops.hip", "tmix_fused.hip", "attention.hip", "wkv7_step.hip", "ln_fused.hip", "wkv6_capi.hip", "loss_fused.hip", "gemv_decode.hip", "decode_fused.hip", "lora_wgrad.hip", "visual_ops.hip", "patch_embed.hip", "image_ops.hip"]
 
 
 def hipcc() -> str:

@@ -97,7 +97,8 @@ __global__ __launch_bounds__(1024) void add_ln_fwd_kernel(long ntok, int C, floa
         V8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o.f[e] = fmaf((v.f[e] - mu) * rs, wv.f[e], bv.f[e]);
-        if (act) *reinterpret_cast<uint4*>(y + (yrow ? yrow[n] : n) * C + c0) = pack8(o);      // yrow: scatter into a larger tensor
+        const long orow = yrow ? yrow[n] : n;                  // yrow: scatter into a larger tensor; a negative row is dropped
+        if (act && orow >= 0) *reinterpret_cast<uint4*>(y + orow * C + c0) = pack8(o);
         if (threadIdx.x == 0) { mean[n] = mu; rstd[n] = rs; }
     }
 }
@@ -121,14 +122,14 @@ __global__ __launch_bounds__(1024) void add_ln_bwd_kernel(long ntok, int C, cons
     uint4 ny = z4, nx = z4, nr = z4;
     float nmu = 0.f, nrs = 0.f;
     if (lo < hi) {
-        if (act) { ny = ldg(dy + (yrow ? yrow[lo] : lo) * C + c0); nx = ldg(xn + lo * C + c0); if (dres) nr = ldg(dres + lo * C + c0); }
+        if (act) { const long r = yrow ? yrow[lo] : lo; ny = r >= 0 ? ldg(dy + r * C + c0) : z4; nx = ldg(xn + lo * C + c0); if (dres) nr = ldg(dres + lo * C + c0); }
         nmu = mean[lo]; nrs = rstd[lo];
     }
     for (long n = lo; n < hi; ++n) {
         const uint4 cy = ny, cx = nx, cr = nr;
         const float mu = nmu, rs = nrs;
         if (n + 1 < hi) {
-            if (act) { ny = ldg(dy + (yrow ? yrow[n + 1] : n + 1) * C + c0); nx = ldg(xn + (n + 1) * C + c0); if (dres) nr = ldg(dres + (n + 1) * C + c0); }
+            if (act) { const long r = yrow ? yrow[n + 1] : n + 1; ny = r >= 0 ? ldg(dy + r * C + c0) : z4; nx = ldg(xn + (n + 1) * C + c0); if (dres) nr = ldg(dres + (n + 1) * C + c0); }
             nmu = mean[n + 1]; nrs = rstd[n + 1];
         }
         const V8 d = unpack8(cy), xv = unpack8(cx);
@@ -203,7 +204,9 @@ int vrwkv_add_ln_fwd_bf16(long ntok, int C, float eps, const void* x, const void
 
 // LayerNorm of the projector output written straight into the rows of the token-embedding tensor that hold the image
 // placeholders (MLPWithContextGating's ln_v + the masked scatter of preparing_embedding, src/model.py:338,485-493):
-// out[row_index[n]] = LN(x[n]).  row_index: device int64, strictly increasing.
+// out[row_index[n]] = LN(x[n]).  row_index: device int64, distinct rows; a NEGATIVE entry drops feature row n (the sample
+// had fewer placeholders than features -- the reference truncates the features, src/model.py:487-491): nothing is written
+// for it and in the backward it receives a zero gradient and does not contribute to dgamma / dbeta.
 int vrwkv_ln_scatter_fwd_bf16(long ntok, int C, float eps, const void* x, const void* w, const void* b, const long* row_index,
                               void* out, float* mean, float* rstd, void* stream) {
     if (ntok <= 0 || !x || !w || !b || !row_index || !out || !mean || !rstd) return VRWKV_EINVAL;

@@ -61,7 +61,7 @@ class _Bucket:
 class Zero1Engine:
     def __init__(self, model: torch.nn.Module, lr: float = 1e-4, betas=(0.9, 0.99), eps: float = 1e-8,
                  weight_decay: float = 0.0, grad_clip: float = 1.0, bucket_mb: float = 200.0,
-                 process_group=None, overlap: bool = True, force_collectives: bool = False):
+                 process_group=None, overlap: bool = True, force_collectives: bool = False, async_gather: bool = False):
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.grad_clip = grad_clip
@@ -78,6 +78,11 @@ class Zero1Engine:
         self.dtype = params[0].dtype
         self.on_gpu = self.device.type == "cuda"
         self.overlap = overlap and self.on_gpu and self.collective
+        # async_gather=False (default): step() returns with the updated parameters visible to the compute stream -- anything
+        # may read them (state_dict / torch.save, the decode path's raw-pointer GEMV kernels and cached transposed weights,
+        # graph capture).  async_gather=True: step() returns while the all-gather still runs on the communication stream and
+        # only module forwards (pre-hooks) wait for it; every other reader must call wait_params() first.
+        self.async_gather = bool(async_gather) and self.overlap
         # Lay the flat buffer out in the order the backward produces the gradients, so that buckets fill front to back:
         # reverse registration order for the language model (head, blocks N-1 .. 0), and whatever feeds the language model's
         # INPUT (the image projector `proj`, the embedding) last -- their gradients only exist when the backward has walked
@@ -149,12 +154,19 @@ class Zero1Engine:
         self._gather_event = None
         self.generation = 0
         self._wait_hooks = []
-        if self.collective and self.on_gpu:
+        if self.async_gather:
             # the parameter all-gather runs on the side stream; whoever first touches a trainable parameter in the next
-            # forward waits for it (the frozen ViT encode ahead of the projector overlaps with it)
-            for mod in model.modules():
-                if any(p.requires_grad for p in mod.parameters(recurse=False)):
-                    self._wait_hooks.append(mod.register_forward_pre_hook(lambda m, a: self.wait_params()))
+            # forward waits for it (the frozen ViT encode ahead of the projector overlaps with it).  Hooks sit on the model, its
+            # children and grandchildren that hold trainable parameters (`rwkv`, `rwkv.emb`, `rwkv.head`, `proj`, `proj.gate` ..):
+            # about ten Python calls per step instead of one per leaf module.  Calling a deeper sub-module directly (e.g.
+            # `model.rwkv.blocks[3](x)`) right after step() needs an explicit wait_params().
+            def trainable(mod):
+                return any(p.requires_grad for p in mod.parameters())
+            kids = [c for c in model.children() if trainable(c)]
+            own = any(p.requires_grad for p in model.parameters(recurse=False))
+            hooked = ([model] if own or not kids else []) + kids + [g for c in kids for g in c.children() if trainable(g)]
+            for mod in hooked:
+                self._wait_hooks.append(mod.register_forward_pre_hook(lambda m, a: self.wait_params()))
         self._reset_pending()
 
     # ------------------------------------------------------------------ gradient reduction
@@ -230,19 +242,15 @@ class Zero1Engine:
         backend = dist.get_backend(self.pg)
         if backend == "nccl":
             dist.reduce_scatter_tensor(piece, buf, op=dist.ReduceOp.SUM, group=self.pg)   # in place on own piece
-        else:   # gloo has no reduce-scatter: all-reduce then keep the own slice (same result)
-            if buf.dtype == torch.bfloat16:
-                tmp = buf.float()
-                dist.all_reduce(tmp, group=self.pg)
-                buf.copy_(tmp)
-            else:
-                dist.all_reduce(buf, group=self.pg)
+        else:   # gloo has no reduce-scatter: all-reduce in the buffer's own dtype (bf16 sums in bf16, like RCCL), keep the own slice
+            dist.all_reduce(buf, group=self.pg)
 
     # ------------------------------------------------------------------ optimizer step
     @torch.no_grad()
     def step(self, lr: Optional[float] = None):
         """Finish gradient reduction, clip to `grad_clip` (global L2 norm), AdamW on the owned pieces, publish
-        the updated bf16 parameters.  Returns the pre-clip global gradient norm."""
+        the updated bf16 parameters.  Returns the pre-clip global gradient norm as a 0-dim float32 tensor on the engine's
+        device on every path (float() of it synchronises; the step itself does not)."""
         lr = self.lr if lr is None else lr
         self.step_count += 1
         self.wait_params()
@@ -274,10 +282,11 @@ class Zero1Engine:
         if self.on_gpu and self.dtype == torch.bfloat16:
             for b in self.buckets:               # clip factor formed on the device from self._sq: no host synchronisation
                 self._adamw(b, lr, None, inv_world, clip)
-            gnorm = self._sq.sqrt() * inv_world   # device tensor (float(gnorm) synchronises; the step itself does not)
+            gnorm = (self._sq.sqrt() * inv_world).reshape(())
         else:
-            gnorm = float(self._sq.sqrt()) * inv_world
-            scale = inv_world * (min(1.0, clip / (gnorm + 1e-6)) if clip > 0 else 1.0)
+            gn = float(self._sq.sqrt()) * inv_world
+            gnorm = torch.tensor(gn, dtype=torch.float32, device=self.device)
+            scale = inv_world * (min(1.0, clip / (gn + 1e-6)) if clip > 0 else 1.0)
             for b in self.buckets:
                 self._adamw(b, lr, scale, inv_world, clip)
         if self.collective:
@@ -289,6 +298,8 @@ class Zero1Engine:
                     self._all_gather()
                     self._gather_event = torch.cuda.Event()
                     self._gather_event.record(self.comm_stream)
+                if not self.async_gather:
+                    self.wait_params()
             else:
                 self._all_gather()
         from . import param_state

@@ -628,8 +628,11 @@ class _LnScatter(torch.autograd.Function):
                                                    w.data_ptr(), dy.data_ptr(), dwb.data_ptr(), ws.data_ptr(), _stream(y)), "vrwkv_ln_gather_bwd_bf16")
         d_emb = None
         if ctx.needs_input_grad[0]:                    # rows that were overwritten do not reach the embedding
-            d_emb = dout.clone()
-            d_emb.index_fill_(0, row_index, 0)
+            R = dout.shape[0]                          # dropped features carry row -1: they zero a scratch row past the end
+            d_emb = torch.empty(R + 1, C, dtype=dout.dtype, device=dout.device)
+            d_emb[:R] = dout
+            d_emb.index_fill_(0, torch.where(row_index < 0, R, row_index), 0)
+            d_emb = d_emb[:R]
         return d_emb, dy, dwb[0].to(w.dtype), dwb[1].to(w.dtype), None, None
 
 
@@ -664,7 +667,10 @@ def cached_padded_patch_weight(module, weight):
     """The padded weight kept on the module that owns `weight` (frozen towers: built once); rebuilt when the parameter
     is modified in place, replaced, or an optimizer step bumps the process-wide parameter generation."""
     from . import param_state
-    key = (weight.data_ptr(), weight._version, param_state.generation(), tuple(weight.shape), weight.device)
+    # the optimizer generation only matters for trainable weights (it is bumped every step; the frozen towers' weights are
+    # not in the ZeRO flat buffer and data_ptr / _version / shape identify them)
+    gen = param_state.generation() if weight.requires_grad else -1
+    key = (weight.data_ptr(), weight._version, gen, tuple(weight.shape), weight.device)
     hit = getattr(module, "_padded_patch_weight", None)
     if hit is None or hit[0] != key:
         hit = (key, padded_patch_weight(weight))

@@ -19,6 +19,8 @@ PROTOTYPES = {
     "vrwkv_wkv7_forward_bf16": (_c_int, [_c_int] * 3 + [_c_void_p] * 10),
     "vrwkv_wkv7_backward_bf16": (_c_int, [_c_int] * 3 + [_c_void_p] * 16),
     "vrwkv_wkv7_backward_segments_bf16": (_c_int, [_c_int] * 4 + [_c_void_p] * 18),
+    "vrwkv_wkv7_forward_host": (_c_int, [_c_int] * 4 + [_c_void_p] * 9 + [_c_int]),
+    "vrwkv_wkv7_backward_host": (_c_int, [_c_int] * 4 + [_c_void_p] * 15 + [_c_int]),
     "vrwkv_wkv6_ckpt_floats": (_c_long, [_c_int] * 3),
     "vrwkv_wkv6_forward_bf16": (_c_int, [_c_int] * 4 + [_c_void_p] * 8),
     "vrwkv_wkv6_backward_bf16": (_c_int, [_c_int] * 4 + [_c_void_p] * 13),

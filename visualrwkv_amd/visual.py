@@ -118,20 +118,32 @@ class VisualRWKV(nn.Module):
     def preparing_embedding(self, samples):
         if "images" not in samples:
             return self.rwkv.emb(samples["input_ids"]), samples["labels"]
-        input_embeds = self.rwkv.emb(samples["input_ids"])
-        B, Ln, D = input_embeds.shape
-        input_embeds = input_embeds.view(B * Ln, D)
-        selected = samples["input_ids"].view(B * Ln) == IMAGE_TOKEN_INDEX
         from . import fused
-        if (getattr(self.args, "fused", False) and isinstance(getattr(self, "proj", None), MLPWithContextGating) and fused.visual_supported(input_embeds)
-                and not getattr(self.args, "check_image_tokens", True) and self.proj.ln_v.weight.dtype == torch.bfloat16 and D % 64 == 0):
-            # GPU path: ln_v of the projector writes straight into the placeholder rows (no masked_scatter, no host sync:
-            # the row list comes from a stable sort of the mask; the caller vouches for the token count, as the bench does)
+        ids = samples["input_ids"]
+        B, Ln = ids.shape
+        D = self.rwkv.emb.weight.shape[1]
+        selected = ids.reshape(B * Ln) == IMAGE_TOKEN_INDEX
+        if (getattr(self.args, "fused", False) and isinstance(getattr(self, "proj", None), MLPWithContextGating) and ids.is_cuda
+                and self.rwkv.emb.weight.dtype == torch.bfloat16 and not getattr(self.args, "check_image_tokens", True)
+                and self.proj.ln_v.weight.dtype == torch.bfloat16 and D % 64 == 0):
+            # GPU path: ln_v of the projector writes straight into the placeholder rows (no masked_scatter, no host sync: the
+            # row list comes from a stable sort of the mask).  The frozen towers run BEFORE the first trainable module is
+            # touched, so the ZeRO-1 parameter all-gather of the previous step (dp.py) overlaps the ViT encode.
             feats = self.encode_images(samples["images"], normed=False)
             feats = feats.reshape(-1, feats.shape[-1])
-            rows = torch.argsort(~selected, stable=True)[:feats.shape[0]]
+            input_embeds = self.rwkv.emb(ids).view(B * Ln, D)
+            n_feat = feats.shape[0]
+            if n_feat > B * Ln:                              # more features than tokens at all: truncate like the reference
+                feats, n_feat = feats[:B * Ln], B * Ln
+            rows = torch.argsort(~selected, stable=True)[:n_feat]
+            # fewer placeholders than features (a multi-image sample truncated at ctx_len): the reference keeps the first
+            # n_sel features and warns (model.py:487-491).  Same result without a host synchronisation: the surplus
+            # features get row -1, which the kernels drop in both directions -- they never overwrite text embeddings.
+            rows = torch.where(selected[rows], rows, torch.full_like(rows, -1))
             input_embeds = fused.ln_scatter(input_embeds, feats, self.proj.ln_v, rows)
             return input_embeds.view(B, Ln, D), samples["labels"]
+        input_embeds = self.rwkv.emb(ids)
+        input_embeds = input_embeds.view(B * Ln, D)
         image_features = self.encode_images(samples["images"])
         image_features = image_features.view(-1, image_features.shape[-1])
         n_sel = int(selected.sum()) if getattr(self.args, "check_image_tokens", True) else image_features.shape[0]

@@ -119,10 +119,46 @@ def _backward_hip(w, q, k, v, z, a, dy, s, sa, dw, dq, dk, dv, dz, da):
     hip_lib.check(rc, "vrwkv_wkv7_backward_bf16")
 
 
+HOST_THREADS = int(os.environ.get("VRWKV_HOST_THREADS", "0"))     # 0 = every hardware thread
+
+
+def _host_dtype(w, tensors, names):
+    """CPU key: bf16 (the op's contract) or float32 (BASELINE config 1, RWKV_FLOAT_MODE=fp32) activations."""
+    if w.dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError(f"wind_backstepping (CPU): activations must be bfloat16 or float32, got {w.dtype}")
+    B, T, H = _dims(w)
+    for n, t in zip(names, tensors):
+        if t.dtype != w.dtype:
+            raise TypeError(f"wind_backstepping (CPU): {n} is {t.dtype}, expected {w.dtype}")
+        if tuple(t.shape) != (B, T, H, HEAD_SIZE) or not t.is_contiguous():
+            raise ValueError(f"wind_backstepping (CPU): {n} must be contiguous {(B, T, H, HEAD_SIZE)}, got {tuple(t.shape)}")
+        if t.device.type != "cpu":
+            raise ValueError("wind_backstepping: all tensors must live on the same device")
+    return B, T, H, 0 if w.dtype == torch.bfloat16 else 1
+
+
+def _forward_host(w, q, k, v, z, a, y, s, sa):
+    """`CPU` dispatch key (the reference has none, cuda/wkv7_op.cpp:26): csrc/wkv7_host.hip on the host cores."""
+    B, T, H, code = _host_dtype(w, (w, q, k, v, z, a, y), "wqkvzay")
+    _check_state(s, sa, B, T, H, w.device)
+    rc = hip_lib.load().vrwkv_wkv7_forward_host(B, T, H, code, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                                z.data_ptr(), a.data_ptr(), y.data_ptr(), s.data_ptr(), sa.data_ptr(), HOST_THREADS)
+    hip_lib.check(rc, "vrwkv_wkv7_forward_host")
+
+
+def _backward_host(w, q, k, v, z, a, dy, s, sa, dw, dq, dk, dv, dz, da):
+    names = ("w", "q", "k", "v", "z", "a", "dy", "dw", "dq", "dk", "dv", "dz", "da")
+    B, T, H, code = _host_dtype(w, (w, q, k, v, z, a, dy, dw, dq, dk, dv, dz, da), names)
+    _check_state(s, sa, B, T, H, w.device)
+    rc = hip_lib.load().vrwkv_wkv7_backward_host(B, T, H, code, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), z.data_ptr(),
+                                                 a.data_ptr(), dy.data_ptr(), s.data_ptr(), sa.data_ptr(), dw.data_ptr(), dq.data_ptr(),
+                                                 dk.data_ptr(), dv.data_ptr(), dz.data_ptr(), da.data_ptr(), HOST_THREADS)
+    hip_lib.check(rc, "vrwkv_wkv7_backward_host")
+
+
 def _no_cpu(*args):
-    raise NotImplementedError(
-        "wind_backstepping has no CPU implementation (neither does the reference: cuda/wkv7_op.cpp:26 "
-        "registers the CUDA key only). Move the tensors to an MI355X device.")
+    raise NotImplementedError("this WKV7 entry point (stateful step / prefill) has no CPU implementation; move the tensors to an "
+                              "MI355X device.  The training op torch.ops.wind_backstepping does run on CPU tensors.")
 
 
 def _register():
@@ -135,8 +171,8 @@ def _register():
     lib.define(_BWD_SCHEMA)
     lib.impl("forward", _forward_hip, "CUDA")
     lib.impl("backward", _backward_hip, "CUDA")
-    lib.impl("forward", _no_cpu, "CPU")
-    lib.impl("backward", _no_cpu, "CPU")
+    lib.impl("forward", _forward_host, "CPU")
+    lib.impl("backward", _backward_host, "CPU")
     return lib
 
 
@@ -150,7 +186,8 @@ class WindBackstepping(torch.autograd.Function):
     def forward(ctx, w, q, k, v, z, b):
         B, T, H, C = w.shape
         assert T % CHUNK_LEN == 0
-        assert all(i.dtype == torch.bfloat16 for i in [w, q, k, v, z, b])
+        # bf16 as in the reference; float32 only for the CPU key (BASELINE config 1, RWKV_FLOAT_MODE=fp32)
+        assert all(i.dtype == torch.bfloat16 or (i.dtype == torch.float32 and not i.is_cuda) for i in [w, q, k, v, z, b])
         assert all(i.is_contiguous() for i in [w, q, k, v, z, b])
         P = tparallel_segments(B, H, T, forward=True) if TPARALLEL_BWD and w.is_cuda else 1
         if P > 1:                                       # one long sequence: sequence-parallel forward
@@ -165,9 +202,9 @@ class WindBackstepping(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        assert all(i.dtype == torch.bfloat16 for i in [dy])
-        assert all(i.is_contiguous() for i in [dy])
         w, q, k, v, z, b, s, sa = ctx.saved_tensors
+        assert all(i.dtype == w.dtype for i in [dy])
+        assert all(i.is_contiguous() for i in [dy])
         if TPARALLEL_BWD and w.is_cuda:                 # few heads -> sequence-parallel backward
             B, T, H, _ = w.shape
             P = tparallel_segments(B, H, T)
