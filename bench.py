@@ -394,7 +394,7 @@ def main():
             ms = sum(x for x, _ in kinds["bwd"]) / len(kinds["bwd"])
             elems = kinds["bwd"][0][1]
             ach = elems * BWD_B / ms / 1e6
-            out["roofline"] = {"bound": "hbm", "kernel": "wkv7v5::bwd_kernel_v5", "achieved": ach, "peak": HBM_PEAK_GBPS,
+            out["roofline"] = {"bound": "hbm", "kernel": "wkv7v6::bwd_kernel_v6", "achieved": ach, "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
                                "avg_ms": ms, "launches": len(kinds["bwd"]), "algorithmic_bytes": elems * BWD_B}
             if "fwd" in kinds:

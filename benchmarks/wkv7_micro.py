@@ -92,6 +92,7 @@ if __name__ == "__main__":
     ap.add_argument("--H", type=int, default=32)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--variants", type=int, nargs="+", default=[-1])
+    ap.add_argument("--bwd-variant", type=int, default=-1)
     args = ap.parse_args()
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
@@ -99,7 +100,7 @@ if __name__ == "__main__":
     print(json.dumps({"stream_copy_GBps": copy, "frac_of_peak": copy / HBM_PEAK_GBPS}))
     for B in args.B:
         for var in args.variants:
-            r = time_wkv7(B, args.T, args.H, iters=args.iters, variant=var)
+            r = time_wkv7(B, args.T, args.H, iters=args.iters, variant=var, bwd_variant=args.bwd_variant)
             r["variant"] = var
             r["fwd_frac_of_copy"], r["bwd_frac_of_copy"] = r["fwd_GBps"] / copy, r["bwd_GBps"] / copy
             print(json.dumps(r))

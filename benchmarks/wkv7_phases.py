@@ -7,7 +7,7 @@ from benchmarks.wkv7_micro import synth_inputs
 from visualrwkv_amd import hip_lib
 
 FWD = ["c_top", "c_main1", "c_waitA", "c_store_y_sa", "c_supdate_store_s", "c_waitB", "-", "-", "p_prep", "p_waitA", "p_scores", "p_waitB"]
-BWD5 = ["c_top", "c_isplit", "c_waitX", "c_jsplit", "c_waitY", "c_seg3_tail", "c_waitZ", "-", "p_top", "p_prepA", "p_waitX", "p_prepB", "p_dM", "p_waitY", "p_scores", "p_waitZ"]
+BWD5 = ["c_top", "c_isplit", "c_waitX", "c_jsplit", "c_waitY", "c_seg3_tail", "c_waitZ", "realtime_100MHz", "p_top", "p_prepA", "p_waitX", "p_prepB", "p_dM", "p_waitY", "p_scores", "p_waitZ"]
 
 def run(B=8, T=2624, H=32, bwd_variant=-1, fwd_variant=-1):
     lib = hip_lib.load()
@@ -19,16 +19,24 @@ def run(B=8, T=2624, H=32, bwd_variant=-1, fwd_variant=-1):
     g = [torch.empty_like(w) for _ in range(6)]
     st = torch.cuda.current_stream().cuda_stream
     out = {}
-    for bw, names in ((0, FWD), (1, BWD5)):
-        dbg = torch.zeros(16, dtype=torch.int64, device=dev)
+    BWD6 = ["I_scores_dM", "I_flagwait", "I_isplit", "I_barrier", "I_top", "J_jsplit", "J_dMwait", "J_products", "J_barrier", "J_top",
+            "P_tail", "P_prep", "P_drain", "P_barrier", "P_top", "realtime_100MHz", "J_js_split", "J_js_outputs", "I_is_dSA_dR", "I_is_dV"]
+    for bw, names in ((0, FWD), (1, BWD5), (2, BWD6)):
+        dbg = torch.zeros(32, dtype=torch.int64, device=dev)
         rc = lib.vrwkv_wkv7_profile_bf16(bw, B, T, H, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), z.data_ptr(), a.data_ptr(),
                                          dy.data_ptr(), y.data_ptr(), s.data_ptr(), sa.data_ptr(), *[x.data_ptr() for x in g], dbg.data_ptr(), st)
         assert rc == 0, rc
         torch.cuda.synchronize()
         d = dbg.cpu().tolist()
         nch = T // 16
-        out["bwd" if bw else "fwd"] = {n: round(d[i] / nch) for i, n in enumerate(names)}
-        out[("bwd" if bw else "fwd") + "_total_per_chunk"] = round(sum(d) / nch)
+        key = ["fwd", "bwd", "bwd_v6"][bw]
+        out[key] = {n: round(d[i] / nch) for i, n in enumerate(names)}
+        out[key + "_total_per_chunk"] = round(sum(d[:15]) / nch)
+        if bw == 2 and d[15] > 0:
+            out["bwd_v6_shader_clock_GHz"] = round(sum(d[0:5]) / (d[15] * 10.0), 3)
+            out["bwd_v6_cycles_per_chunk"] = round(sum(d[0:5]) / nch)
+        if bw == 1 and d[7] > 0:      # shader clock while this kernel runs: consumer-wave cycles of workgroup 0 / its life on the 100 MHz counter
+            out["bwd_shader_clock_GHz"] = round(sum(d[:7]) / (d[7] * 10.0), 3)
     return out
 
 if __name__ == "__main__":

@@ -6,7 +6,7 @@ B=${1:-8}; OUT=${2:-gpurun_out/pmc}; VAR=${3:--1}; R=$PWD
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 run() { # name counters...
   n=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/$OUT/$n -o p -- python $R/benchmarks/wkv7_micro.py --B $B --iters 2 --variants $VAR > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/$OUT/$n -o p -- python $R/benchmarks/wkv7_micro.py --B $B --iters 2 --variants $VAR --bwd-variant ${BWDVAR:--1} > /dev/null 2>&1
 }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY
 run sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE

@@ -6,6 +6,7 @@
 #include <wkv7_chunked_bwd.h>
 #include <wkv7_fwd_v3.h>
 #include <wkv7_bwd_v3.h>
+#include <wkv7_bwd_v6.h>
 #include <wkv7_bwd_v5.h>
 #include <wkv6_chunked.h>
 
@@ -41,6 +42,7 @@ int emu_wkv7_backward_chunked(int B, int T, int H, const void* w, const void* q,
     const dim3 grid((unsigned)(B * H));
     if (mode == 2) { emu::launch(grid, dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 2>(p); }); return (int)sizeof(wkv7c::LdsB3); }
     if (mode == 6) { emu::launch(grid, dim3(512), [&] { wkv7v5::bwd_kernel_v5<false, 2 + 4 + 128>(p); }); return (int)sizeof(wkv7v5::LdsV5); }
+    if (mode == 7) { emu::launch(grid, dim3(768), [&] { wkv7v6::bwd_kernel_v6<false>(p); }); return (int)sizeof(wkv7v6::LdsV6); }   // three-stage wave pipeline
     return -1;
 }
 

@@ -217,6 +217,7 @@ DEVFN char* dyn_lds() { static __attribute__((aligned(16))) char buf[160 * 1024]
 
 template <int P> DEVFN void wave_priority() {}
 DEVFN unsigned long long clock64_() { return 0; }
+DEVFN unsigned long long realtime64_() { return 0; }
 DEVFN void block_sync() { emu::block_barrier(); }
 DEVFN void block_sync_lds() { emu::block_barrier(); }
 DEVFN void wave_lds_fence() { emu::wave_barrier(); }

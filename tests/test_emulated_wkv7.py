@@ -44,11 +44,12 @@ def test_forward_from_state(emu_lib):
     assert rel_rms(y2.double(), y_ref0) < 4e-3
 
 
-@pytest.mark.parametrize("mode", [2, 6])
-def test_backward_chunked(emu_lib, mode):
+@pytest.mark.parametrize("mode,T", [(2, 48), (6, 48), (7, 16), (7, 32), (7, 96)])
+def test_backward_chunked(emu_lib, mode, T):
     """Chunked MFMA backward kernels run lane-exactly on the host: 2 = the predecessor (wkv7_bwd_v3.h, workgroup barriers,
-    bf16x3 doubling), 6 = the default second-generation schedule (wkv7_bwd_v5.h)."""
-    B, T, H = 1, 48, 2
+    bf16x3 doubling), 6 = the second-generation schedule (wkv7_bwd_v5.h), 7 = the three-stage wave pipeline (wkv7_bwd_v6.h;
+    1, 2 and 6 chunks: pipeline shorter than, equal to and longer than its depth)."""
+    B, H = 1, 2
     w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=7 + mode)
     _, s, sa = wkv7_c.forward(w, q, k, v, z, a)
     ref = wkv7_c.backward(w, q, k, v, z, a, dy, s, sa)

@@ -89,6 +89,36 @@ def test_fused_projector_pool_scatter_match_eager_and_fixture(gold):
         assert rel_rms(p.grad.float(), gref[n].float()) < 2e-2, n
 
 
+def test_fused_scatter_with_fewer_placeholders_than_features():
+    """A multi-image sample truncated at ctx_len has fewer <image> tokens than projected features.  The reference keeps
+    the first n_sel features (model.py:487-491); the sync-free GPU path must do the same -- surplus features are dropped
+    in both directions and never overwrite text embeddings (they used to land on the first text rows)."""
+    from types import SimpleNamespace as NS
+    from visualrwkv_amd.visual import MLPWithContextGating, VisualRWKV
+    torch.manual_seed(1)
+    D, C, Ln, n_feat, n_sel = 64, 128, 48, 32, 20
+    proj = MLPWithContextGating(D, C).cuda().bfloat16()
+    emb = nn.Embedding(65536, C).cuda().bfloat16()
+    ids = torch.randint(0, 1000, (1, Ln), device="cuda")
+    ids[0, 5:5 + n_sel] = 65535
+    pre = torch.randn(n_feat, D, device="cuda").bfloat16()
+    holder = NS(rwkv=NS(emb=emb), proj=proj, args=NS(check_image_tokens=False, fused=True),
+                encode_images=lambda images, normed=True: (proj(pre) if normed else proj.pre_norm(pre)).view(1, n_feat, C))
+    y, _ = VisualRWKV.preparing_embedding(holder, {"input_ids": ids, "labels": ids, "images": {}})
+    gout = torch.randn_like(y)
+    y.backward(gout)
+    got = {n: p.grad.clone() for n, p in proj.named_parameters()}
+    proj.zero_grad()
+    # the reference's statement: truncate the features to the placeholder count, masked_scatter
+    sel = (ids.view(-1) == 65535)
+    ref = emb(ids).view(Ln, C).masked_scatter(sel[:, None], proj(pre)[:n_sel])
+    ref.backward(gout.view(Ln, C))
+    assert torch.equal(y.view(Ln, C)[~sel], ref[~sel])           # text rows untouched, bit-exact
+    assert rel_rms(y.view(Ln, C)[sel].float(), ref[sel].float()) < 1e-2
+    for n, p in proj.named_parameters():
+        assert rel_rms(got[n].float(), p.grad.float()) < 2e-2, n
+
+
 def test_sam_encoder_gpu(gold):
     """Scaled SAM configuration of the fixture (128^2 input, window 3, one global block) through the product path."""
     from visualrwkv_amd.vit import SamImageEncoder

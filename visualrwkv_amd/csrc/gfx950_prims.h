@@ -166,6 +166,8 @@ template <int P> DEVFN void wave_priority() { __builtin_amdgcn_s_setprio(P); }
 
 // shader clock (s_memtime), for in-kernel phase timing
 DEVFN unsigned long long clock64_() { return __builtin_readcyclecounter(); }
+// constant-rate counter (s_memrealtime, 100 MHz): shader cycles / its ticks = the clock the kernel actually ran at
+DEVFN unsigned long long realtime64_() { return (unsigned long long)wall_clock64(); }
 
 // ---------------------------------------------------------------- LDS transpose read (gfx950)
 // ds_read_b64_tr_b16: every lane supplies the LDS address of 4 consecutive 16-bit elements; inside each group of 16

@@ -302,6 +302,7 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
     const float* sbase = p.s + (size_t)bh * nchunk * N * N;
     const bool lite = TPAR && p.ds_out != nullptr && p.ds_in == nullptr;        // wave-uniform; constant false without TPAR
     WKV_STAMP_DECL
+    const unsigned long long rt0_ = PROF ? realtime64_() : 0ull;       // constant-rate (100 MHz) counter: cycles / time = shader clock
 
     if (wave >= 4) {
         // ================================================================== producers (one chunk ahead; loads only)
@@ -618,6 +619,7 @@ __global__ __launch_bounds__(512) void bwd_kernel_v5(BwdArgs p) {
             *reinterpret_cast<float4*>(dout + (size_t)(16 * wave + c16) * N + tix(x, 4 * g)) = make_float4(dS1[x][0], dS1[x][1], dS1[x][2], dS1[x][3]);
     }
     WKV_STAMP_FLUSH(0, 0, 7)
+    if (PROF && blockIdx.x == 0 && tid == 0) p.dbg[7] = realtime64_() - rt0_;   // ticks of the 100 MHz counter over workgroup 0's life
 }
 
 }  // namespace wkv7v5

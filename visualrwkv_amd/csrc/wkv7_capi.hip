@@ -9,6 +9,7 @@
 #include <wkv7_fwd_v3.h>
 #include <wkv7_bwd_v3.h>
 #include <wkv7_bwd_v5.h>
+#include <wkv7_bwd_v6.h>
 
 namespace {
 
@@ -17,6 +18,9 @@ int g_bwd_variant = -1;
 // T chain on the bf16 matrix core (2) + producer priority 2 (4; same-box A/B: 1.18 -> 1.09 ms) + priorities swapped in
 // segment 1, where the producers have ~1.2k cycles of slack per chunk and the consumers none (128; 1.09 -> 1.04 ms)
 constexpr int BWD_V5_MODE = 2 + 4 + 128;
+// same-box A/B on MI355X, B=16 x 2624 x 32 heads: micro-benchmark (random inputs) 1.042 -> 0.993 ms, inside the training step
+// (bench.py, VRWKV_BWD_VARIANT=5 / 6) 0.981 -> 0.872 ms
+constexpr bool BWD_DEFAULT_V6 = true;
 constexpr int BWD_V3_MODE = 2;    // same-process A/B on MI355X (benchmarks/wkv7_ab.py): counters +1..3 % slower, bf16x3 doubling -1 %
 
 inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
@@ -55,7 +59,7 @@ int vrwkv_wkv7_set_forward_variant(int variant) {
 }
 
 int vrwkv_wkv7_set_backward_variant(int variant) {
-    if (variant != -1 && variant != 4) return VRWKV_EINVAL;      // -1: wkv7_bwd_v5.h; 4: predecessor wkv7_bwd_v3.h
+    if (variant != -1 && variant != 4 && variant != 5 && variant != 6 && !(variant >= 60 && variant < 68)) return VRWKV_EINVAL;   // see include/visualrwkv_hip.h
     g_bwd_variant = variant;
     return VRWKV_OK;
 }
@@ -126,6 +130,23 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H, const void* w, const void* q, 
                                            (int)sizeof(wkv7c::LdsB3));
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(kern, grid, dim3(512), sizeof(wkv7c::LdsB3), st, p);
+    } else if (g_bwd_variant == 6 || (g_bwd_variant >= 60 && g_bwd_variant < 68) || (g_bwd_variant == -1 && BWD_DEFAULT_V6)) {
+        // three-stage wave pipeline, 12 waves (wkv7_bwd_v6.h); 60..67: priority / role-placement experiments
+        void (*kern)(wkv7::BwdArgs) = &wkv7v6::bwd_kernel_v6<false>;
+        switch (g_bwd_variant) {
+            case 61: kern = &wkv7v6::bwd_kernel_v6<false, 0, 0, 1, false, true, 1>; break;     // timing experiments: roles switched off
+            case 62: kern = &wkv7v6::bwd_kernel_v6<false, 0, 0, 1, false, true, 2>; break;
+            case 63: kern = &wkv7v6::bwd_kernel_v6<false, 0, 0, 1, false, true, 4>; break;
+            case 64: kern = &wkv7v6::bwd_kernel_v6<false, 0, 0, 1, false, true, 3>; break;     // J alone
+            case 65: kern = &wkv7v6::bwd_kernel_v6<false, 0, 0, 1, false, true, 5>; break;     // I alone
+            case 66: kern = &wkv7v6::bwd_kernel_v6<false, 0, 0, 1, false, true, 6>; break;     // P alone
+            case 67: kern = &wkv7v6::bwd_kernel_v6<false, 0, 0, 1, false, true, 7>; break;     // barriers only
+            default: break;
+        }
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)sizeof(wkv7v6::LdsV6));
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kern, grid, dim3(768), sizeof(wkv7v6::LdsV6), st, p);
     } else {                                        // default: second-generation schedule (wkv7_bwd_v5.h)
         auto kern = &wkv7v5::bwd_kernel_v5<false, BWD_V5_MODE>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -179,6 +200,14 @@ int vrwkv_wkv7_profile_bf16(int backward, int B, int T, int H, const void* w, co
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsF));
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL((wkv7c::fwd_kernel_v3<true, false, 1>), grid, dim3(512), sizeof(wkv7c::LdsF), st, p);
+    } else if (backward == 2) {                     // three-stage pipeline (wkv7_bwd_v6.h): I / J / P wave 0, five stamps each
+        wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
+                        (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
+                        (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da, dbg};
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7v6::bwd_kernel_v6<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7v6::LdsV6));
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((wkv7v6::bwd_kernel_v6<true>), grid, dim3(768), sizeof(wkv7v6::LdsV6), st, p);
     } else {
         wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                         (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,

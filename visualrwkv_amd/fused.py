@@ -405,17 +405,29 @@ def add_ln_supported(x):
     return x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 64 == 0 and x.shape[-1] <= 8192
 
 
-def blocks_forward(rwkv, x):
+def _block_segment(block, x, delta, v_first):
+    """One Block on the (x, pending delta) residual stream: returns (x + delta, ffn output still to be added, v_first)."""
+    x, h = add_ln(x, delta, block.ln1)
+    att_out, v_first = block.att(h, v_first)
+    x, h = add_ln(x, att_out, block.ln2)
+    return x, block.ffn(h), v_first
+
+
+def blocks_forward(rwkv, x, grad_cp=False):
     """All Blocks + ln_out with the residual adds fused into the LayerNorms (same math as Block.forward chained,
-    src/model.py:247-254,313-318): the residual stream is carried as (x, pending delta)."""
+    src/model.py:247-254,313-318): the residual stream is carried as (x, pending delta).  grad_cp: every Block is
+    re-computed in the backward (the reference's default recipe, deepspeed.checkpointing.checkpoint per block,
+    src/model.py:318-319) -- through these same fused kernels, so the recompute and the backward use add_ln / the glue
+    kernels / the WKV7 op, not the eager modules."""
     x = rwkv.blocks[0].ln0(x)
     v_first = torch.empty_like(x)
     delta = None
     for block in rwkv.blocks:
-        x, h = add_ln(x, delta, block.ln1)
-        att_out, v_first = block.att(h, v_first)
-        x, h = add_ln(x, att_out, block.ln2)
-        delta = block.ffn(h)
+        if grad_cp:
+            from torch.utils.checkpoint import checkpoint
+            x, delta, v_first = checkpoint(_block_segment, block, x, delta, v_first, use_reentrant=False)
+        else:
+            x, delta, v_first = _block_segment(block, x, delta, v_first)
     _, h = add_ln(x, delta, rwkv.ln_out)
     return h
 

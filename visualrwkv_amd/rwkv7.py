@@ -296,10 +296,10 @@ class RWKV(nn.Module):
         x = self.pad_left(x, num_tokens_to_pad)
         if args.dropout > 0:
             x = self.drop0(x)
-        if getattr(args, "fused", False) and not (args.grad_cp == 1 and torch.is_grad_enabled()):
+        if getattr(args, "fused", False):
             from . import fused
             if fused.add_ln_supported(x):
-                return fused.blocks_forward(self, x), num_tokens_to_pad
+                return fused.blocks_forward(self, x, grad_cp=args.grad_cp == 1 and torch.is_grad_enabled()), num_tokens_to_pad
         v_first = torch.empty_like(x)
         for block in self.blocks:
             if args.grad_cp == 1 and torch.is_grad_enabled():

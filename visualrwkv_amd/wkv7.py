@@ -161,6 +161,14 @@ def _no_cpu(*args):
                               "MI355X device.  The training op torch.ops.wind_backstepping does run on CPU tensors.")
 
 
+def _apply_variant_env():
+    """VRWKV_BWD_VARIANT / VRWKV_FWD_VARIANT: same-box A/B of kernel generations inside the training step (benchmarks only)."""
+    for env, fn in (("VRWKV_BWD_VARIANT", "vrwkv_wkv7_set_backward_variant"), ("VRWKV_FWD_VARIANT", "vrwkv_wkv7_set_forward_variant")):
+        v = os.environ.get(env)
+        if v is not None:
+            hip_lib.check(getattr(hip_lib.load(), fn)(int(v)), fn)
+
+
 def _register():
     try:
         lib = torch.library.Library("wind_backstepping", "DEF")
@@ -177,6 +185,7 @@ def _register():
 
 
 _LIB = _register()
+_apply_variant_env()
 
 
 class WindBackstepping(torch.autograd.Function):
