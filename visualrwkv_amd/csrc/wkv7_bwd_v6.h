@@ -50,7 +50,7 @@ struct LdsV6 {
     uint16_t dr[2][2][IMG];          // dR hi, lo [t][i] by chunk parity (I waves -> next step's dM and j-split)
     float s0[2][N * N];              // S0 by chunk parity (P waves' LDS-DMA -> next step's j-split)
     ResImg res[2];                   // by chunk parity (J waves -> next step's tail)
-    unsigned flag[4];                // 0: score images of this step written (4 per step)   1: dM written (3 per step)
+    unsigned flag[4];                // 0: M_qa, M_qk, M_zk of this step written (3 per step)   1: dM written (3 per step)   2: T written (1)
 };
 static_assert(sizeof(LdsV6) <= 160 * 1024, "LDS budget");
 
@@ -141,6 +141,15 @@ DEVFN void tail(const ResImg& R, const TailRaw& tr, const BwdArgs& p, size_t u, 
     *out(p.da) = make_uint2(cvt_pk_bf16(da[0], da[1]), cvt_pk_bf16(da[2], da[3]));
 }
 
+// U^T V for 16x16 register matrices in C layout with the operands already split (see wkv7v5::regmm_x3): a level of the
+// doubling uses every matrix twice, so each is split once (4 splits per level instead of 6: -72 VALU on the T chain's wave)
+struct Split16 { uint2 h, l; };
+DEVFN Split16 split16(f32x4 x) { Split16 s; split4(x, s.h, s.l); return s; }
+DEVFN f32x4 regmm_pre(const Split16& u, const Split16& v) {
+    const f32x4 acc = mfma32(mk8(u.h, u.l), mk8(v.h, v.h), zero4());
+    return mfma32(mk8(u.h.x, u.h.y, 0u, 0u), mk8(v.l.x, v.l.y, 0u, 0u), acc);
+}
+
 // ------------------------------------------------------------------------------------------ I: scores, T, score gradients
 // piece 0: T (DZ image of T^T)   1: M_qa   2: M_qk   3: M_zk (DZ image)
 template <bool DBL_BF16>
@@ -176,16 +185,32 @@ DEVFN void scores6(LdsV6& lds, const ChunkImg& B, int piece, int c16, int g, con
             XT[r] = (4 * g + r < c16) ? XT[r] : 0.f;
             Tc[r] = X[r] + ((4 * g + r == c16) ? 1.f : 0.f);
         }
+        if (DBL_BF16) {
+            Split16 sx = split16(X), sxt = split16(XT);
 #pragma unroll
-        for (int level = 0; level < 3; ++level) {
-            // bf16x3 (2 MFMAs of 16 cycles + 24 VALU for the operand splits) or exact f32 (4 MFMAs of 32 cycles, no VALU)
-            const f32x4 XTn = DBL_BF16 ? regmm_x3(X, XT) : regmm_f32x2(X, XT);          // (X^T)^2
-            f32x4 Xn = X;
-            if (level < 2) Xn = DBL_BF16 ? regmm_x3(XT, X) : regmm_f32x2(XT, X);         // X^2
-            const f32x4 D = DBL_BF16 ? regmm_x3(XTn, Tc) : regmm_f32x2(XTn, Tc);         // X_k T
+            for (int level = 0; level < 3; ++level) {
+                const f32x4 XTn = regmm_pre(sx, sxt);                // (X^T)^2
+                f32x4 Xn = X;
+                if (level < 2) Xn = regmm_pre(sxt, sx);              // X^2
+                const Split16 sxtn = split16(XTn);
+                const f32x4 D = regmm_pre(sxtn, split16(Tc));        // X_k T
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Tc[r] += D[r];
-            X = Xn; XT = XTn;
+                for (int r = 0; r < 4; ++r) Tc[r] += D[r];
+                X = Xn; XT = XTn;
+                sxt = sxtn;
+                if (level < 2) sx = split16(Xn);
+            }
+        } else {
+#pragma unroll
+            for (int level = 0; level < 3; ++level) {
+                const f32x4 XTn = regmm_f32x2(X, XT);                // exact f32 matrix core: 4 MFMAs of 32 cycles, no VALU
+                f32x4 Xn = X;
+                if (level < 2) Xn = regmm_f32x2(XT, X);
+                const f32x4 D = regmm_f32x2(XTn, Tc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Tc[r] += D[r];
+                X = Xn; XT = XTn;
+            }
         }
         split4(Tc, hh, ll);                                      // Tc[r] = T[4g+r][c16] -> image[c16][4g+r]
         st16(lds.dz[1] + la.row[0], hh, hh);
@@ -265,6 +290,8 @@ __global__ __launch_bounds__(768) void bwd_kernel_v6(BwdArgs p) {
                 // S0 of chunk cd = s[cd-1] for the j-split of the next step; its buffer was last read two steps ago
                 if (FULL) dma_state(lds.s0[cd & 1], sbase + (size_t)(cd - 1) * N * N, 4 * w, 4 * w + 4, lane);
                 else if (cd >= 0 && cd <= nchunk - 1) dma_state(lds.s0[cd & 1], cd > 0 ? sbase + (size_t)(cd - 1) * N * N : nullptr, 4 * w, 4 * w + 4, lane);
+                // prefetch of the next chunk first, a full step ahead of its use (issued after the prep instead, the P role alone
+                // ran 0.77 -> 0.97 ms: when every CU streams, the loads need most of a step to come back)
                 RawIn nxt;
                 fetch(nxt, cp - 1 > 0 ? cp - 1 : 0);        // unconditional (chunk 0 again past the end): no copies, no early wait
                 if (FULL || (ct >= 0 && ct <= nchunk - 1)) tail(lds.res[ct & 1], q2, p, head_base + (size_t)ct * L * ts, lane_boff, c16, w, g, la);
@@ -287,6 +314,8 @@ __global__ __launch_bounds__(768) void bwd_kernel_v6(BwdArgs p) {
         for (; n < 3 && n < nsteps; ++n) pstep(n, BoolTag<false>{});
         // unrolled by 6 = lcm(queue depth 3, prefetch ping-pong 2): the queue shifts and the raw <- nxt copy become renaming
         // (120 of the ~400 VALU instructions of a step were v_mov)
+        // (unrolling this loop so that the queue shifts and `raw = nxt` become renaming was tried by 2, 3, 4 and 6: the P role's
+        // live set is at the 168-register limit of a 12-wave workgroup and every variant spilled inside the loop: 0.99 -> 1.28 ms)
         for (; n < nchunk; ++n) pstep(n, BoolTag<true>{});
         for (; n < nsteps; ++n) pstep(n, BoolTag<false>{});
         WKV_STAMP_FLUSH(512, 10, 5)
@@ -299,15 +328,15 @@ __global__ __launch_bounds__(768) void bwd_kernel_v6(BwdArgs p) {
         f32x4 dS1[4];                                       // dS1[jb][r] = dS[i = 16w+c16][j = tix(jb, 4g+r)]
 #pragma unroll
         for (int x = 0; x < 4; ++x) dS1[x] = zero4();
-        unsigned n_sc = 0;
+        unsigned n_sc = 0, n_t = 0;
         for (int n = 0; n < nsteps; ++n) {
             const int ci = nchunk - n, cj = ci + 1;         // this role's chunk | the J waves' chunk of this step
             WKV_STAMP(4)
             if (ci >= 0 && ci <= nchunk - 1) {
                 const ChunkImg& B = lds.b[ci % 3];
                 if (!(SKIP & 2)) scores6<TBF16>(lds, B, w, c16, g, la);
-                lds_flag_add(&lds.flag[0]);
-                n_sc += 4;
+                lds_flag_add(&lds.flag[w == 0 ? 2 : 0]);        // T has its own counter: nobody waits for it before dSA is done
+                n_sc += 3; n_t += 1;
             }
             if (w > 0 && cj >= 0 && cj <= nchunk - 1) {     // score gradients of the J waves' chunk (their dR is one step old)
                 const ChunkImg& Bj = lds.b[cj % 3];
@@ -350,6 +379,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v6(BwdArgs p) {
                 split4(dSA, xh, xl);
                 const bf16x8 xhl = mk8(xh, xl);
                 // dR = T^T dSA in both orientations: [t][i] stays in registers, [i][t] (token per lane) goes to LDS
+                lds_flag_wait(&lds.flag[2], n_t);               // T of this chunk (wave 0's doubling chain) is in LDS
                 const bf16x8 t1 = ld16(&lds.dz[1][la.row[0]]), t2 = ld16(&lds.dz[1][la.row[1]]);        // [T_h T_h], [T_l 0]
                 f32x4 dR = mfma32(t1, xhl, zero4());
                 dR = mfma32(t2, xhl, dR);
