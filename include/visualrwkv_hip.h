@@ -160,11 +160,9 @@ int vrwkv_wkv7_step_bf16(int B, int H, const void* w, const void* q, const void*
                          const void* z, const void* a, float* state, void* y, void* stream);
 
 /* Kernel-generation override for tests and A/B benchmarks; -1 restores the default.
- * forward:  -1 = chunked MFMA kernel with producer / consumer waves (csrc/wkv7_fwd_v3.h),
- *            0 = its predecessor, the sequential one-wave-per-head kernel (csrc/wkv7_kernels.h).
- * backward: -1 = the default (see csrc/wkv7_capi.hip), 5 = producer / consumer schedule of 8 waves (csrc/wkv7_bwd_v5.h),
- *            6 = three-stage wave pipeline of 12 waves (csrc/wkv7_bwd_v6.h), 4 = first schedule (csrc/wkv7_bwd_v3.h).
- *            Anything else: VRWKV_EINVAL. */
+ * forward:  only -1 (csrc/wkv7_fwd_v3.h: chunked MFMA kernel with producer / consumer waves).
+ * backward: -1 = the default (6), 6 = three-stage wave pipeline of 12 waves (csrc/wkv7_bwd_v6.h), 5 = producer / consumer
+ *            schedule of 8 waves (csrc/wkv7_bwd_v5.h; also the sequence-parallel kernel).  Anything else: VRWKV_EINVAL. */
 int vrwkv_wkv7_set_forward_variant(int variant);
 int vrwkv_wkv7_set_backward_variant(int variant);
 

@@ -3,9 +3,7 @@
 #include <gfx950_prims.h>   // resolves to tests/emu/gfx950_prims.h (-I order)
 #include <wkv7_kernels.h>
 #include <wkv7_chunked.h>
-#include <wkv7_chunked_bwd.h>
 #include <wkv7_fwd_v3.h>
-#include <wkv7_bwd_v3.h>
 #include <wkv7_bwd_v6.h>
 #include <wkv7_bwd_v5.h>
 #include <wkv6_chunked.h>
@@ -17,8 +15,8 @@ int emu_wkv7_forward(int B, int T, int H, const void* w, const void* q, const vo
     wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                     (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, s, sa};
     dim3 grid((unsigned)(B * H));
-    if (variant == 0) emu::launch(grid, dim3(64), [&] { wkv7::fwd_kernel<16, 8>(p); });                 // scalar predecessor
-    else emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1>(p); });               // default
+    (void)variant;
+    emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1>(p); });
     return 0;
 }
 
@@ -33,14 +31,12 @@ int emu_wkv7_forward_state(int B, int T, int H, const void* w, const void* q, co
 int emu_wkv7_backward_chunked(int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
                               const void* z, const void* a, const void* dy, const float* s, const float* sa,
                               void* dw, void* dq, void* dk, void* dv, void* dz, void* da, int mode) {
-    // mode 2: predecessor (wkv7_bwd_v3.h, bf16x3 doubling); 6: default (wkv7_bwd_v5.h, T chain on the bf16 matrix core)
+    // mode 6: producer / consumer schedule of 8 waves (wkv7_bwd_v5.h); 7: three-stage wave pipeline (wkv7_bwd_v6.h, the default)
     wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                     (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
                     (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
-    static_assert(sizeof(wkv7c::LdsB3) <= 160 * 1024, "LDS budget");
     static_assert(sizeof(wkv7v5::LdsV5) <= 160 * 1024, "LDS budget");
     const dim3 grid((unsigned)(B * H));
-    if (mode == 2) { emu::launch(grid, dim3(512), [&] { wkv7c::bwd_kernel_v3<false, 2>(p); }); return (int)sizeof(wkv7c::LdsB3); }
     if (mode == 6) { emu::launch(grid, dim3(512), [&] { wkv7v5::bwd_kernel_v5<false, 2 + 4 + 128>(p); }); return (int)sizeof(wkv7v5::LdsV5); }
     if (mode == 7) { emu::launch(grid, dim3(768), [&] { wkv7v6::bwd_kernel_v6<false>(p); }); return (int)sizeof(wkv7v6::LdsV6); }   // three-stage wave pipeline
     return -1;

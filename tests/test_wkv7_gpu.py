@@ -44,7 +44,7 @@ def _capi_backward(lib, w, q, k, v, z, a, dy, s, sa):
     return outs
 
 
-@pytest.mark.parametrize("variant", [0, -1])         # scalar predecessor, chunked MFMA default
+@pytest.mark.parametrize("variant", [-1])
 @pytest.mark.parametrize("B,T,H", [(1, 16, 1), (2, 64, 3), (1, 384, 12), (3, 208, 5)])
 def test_forward_parity(hip_lib, dev, B, T, H, variant):
     w, q, k, v, z, a, _ = make_inputs(B, T, H, seed=B * 1000 + T + H)
@@ -60,7 +60,7 @@ def test_forward_parity(hip_lib, dev, B, T, H, variant):
     assert rel_rms(sa.cpu(), sar) < 2e-5
 
 
-@pytest.mark.parametrize("variant", [4, 5, 6, -1])   # wkv7_bwd_v3.h, wkv7_bwd_v5.h (8 waves), wkv7_bwd_v6.h (12-wave pipeline), default
+@pytest.mark.parametrize("variant", [5, 6])          # wkv7_bwd_v5.h (8 waves; also the sequence-parallel kernel), wkv7_bwd_v6.h (12-wave pipeline, default)
 @pytest.mark.parametrize("B,T,H", [(1, 16, 1), (2, 64, 3), (1, 384, 12), (3, 208, 5)])
 def test_backward_parity(hip_lib, dev, B, T, H, variant):
     w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=B * 77 + T + H)

@@ -236,7 +236,7 @@ struct Bwd6Args {
     uint16_t* gu;                   // bf16 (B,H*N): per-sample, summed over the batch by the caller (src/model.py:84)
 };
 
-constexpr int RS6 = 68;             // row stride (floats) of the tail bounce strips (conflict-free, see wkv7_bwd_v3.h)
+constexpr int RS6 = 68;             // row stride (floats) of the tail bounce strips (conflict-free for the float4 column reads)
 struct Lds6B {
     uint16_t rt[2][L][TJ], kh[2][L][TJ], kb[2][L][TJ];        // [t][j] hi,lo
     uint16_t dy[L][TJ], v[L][TJ];                             // [t][i] exact bf16

@@ -1,9 +1,21 @@
 // WKV7 backward, chunked MFMA form, second-generation schedule -- gfx950.
 //
-// Same math as wkv7_chunked_bwd.h (closed-form differentiation of a 16-token chunk from S0 = s[c-1] and the saved sa;
-// reference: VisualRWKV-v7/v7.00/cuda/wkv7_cuda.cu:54-130) and the same producer/consumer split as wkv7_bwd_v3.h
-// (8 waves per (b,h), three barrier-delimited segments per chunk).  What changed is driven by the round-1 counters of
-// that kernel (profiles/r1_wkv7_pmc_b16.txt: VALU:MFMA = 10.5:1, a third of the VALU instructions register moves that
+// Closed-form differentiation of a 16-token chunk from S0 = s[c-1] and the saved sa (oracle/wkv7_chunked.py::backward is
+// the CPU statement, validated to 1e-15 against fp64 autograd; replaces the token-by-token un-stepping of the reference,
+// VisualRWKV-v7/v7.00/cuda/wkv7_cuda.cu:54-130).  With the forward quantities of wkv7_chunked.h and dS = dL/dS_L entering:
+//     dSA = Ab dS^T + M_qa^T dY          Ab = a c_L/c_t, Kb = k c_L/c_t
+//     dR  = (I - M_za)^-T dSA
+//     dV  = Kb dS^T + M_qk^T dY + M_zk^T dR
+//     dM_za = tril_(dR SA^T)  dM_zk = tril_(dR V^T)  dM_qa = tril(dY SA^T)  dM_qk = tril(dY V^T)
+//     dZt = dR S0 + dM_za Ah + dM_zk Kh      dQt = dY S0 + dM_qa Ah + dM_qk Kh
+//     dAh = SA dU + dM_za^T Zt + dM_qa^T Qt  dKh = V dU + dM_zk^T Zt + dM_qk^T Qt     (dU = dS diag(c_L))
+//     dS0 = dU + dY^T Qt + dR^T Zt
+//     dz = dZt c_{t-1}  dq = dQt c_t  da = dAh/c_t  dk = dKh/c_t
+//     g_t = dq q - da a - dk k + dz_{t+1} z_{t+1} (+ sum_i dS (.) S_L at t = L);  dw_raw_t = log(w_t) sum_{r>=t} g_r
+//
+// with a producer/consumer split
+// (8 waves per (b,h), three barrier-delimited segments per chunk).  Its layout choices were driven by the round-1 counters of
+// its predecessor (profiles/r1_wkv7_pmc_b16.txt: VALU:MFMA = 10.5:1, a third of the VALU instructions register moves that
 // assemble MFMA operands from two LDS reads, LDS pipe 45 % busy with 22 % bank conflicts, 100 two-byte LDS scatter
 // stores per chunk for transposed operand copies) and by its phase stamps (j-split 3.0k of 9k cycles per chunk, half of
 // it a vmcnt wait: a wave that both prefetches S0 and stores gradients has to drain its stores before it may use the
@@ -281,7 +293,7 @@ DEVFN void tiles_op(const f32x4* tl, bf16x8* oh, bf16x8* ol) {
 // MODE bit 2 (4): producers at wave priority 2 instead of 1.
 // MODE bit 7 (128): priorities by segment -- in segment 1 the producers drop to 0 and the consumers rise to 1 (the producers
 // have ~1.2k cycles of slack per chunk there and the consumers none); everywhere else the producers stay above the consumers.
-// TPAR: sequence-parallel launch (see wkv7_bwd_v3.h): blockIdx.x = (b*H + h) * nseg + seg, chunks [c_lo, c_hi),
+// TPAR: sequence-parallel launch: blockIdx.x = (b*H + h) * nseg + seg, chunks [c_lo, c_hi),
 // dL/dS enters as ds_in[b,h,seg] and leaves as ds_out[b,h,seg] (both [i][j] fp32).  A launch that only asks for ds_out
 // (ds_in == null: the first pass of the sequence-parallel backward, whose gradients are discarded) runs LITE: only what
 // propagates dL/dS is computed -- no S0 images, no score gradients, no dV, no j-split output products, no tail, no stores.

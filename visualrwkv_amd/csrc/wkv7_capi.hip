@@ -5,9 +5,7 @@
 #include "../../include/visualrwkv_hip.h"
 #include <wkv7_kernels.h>
 #include <wkv7_chunked.h>
-#include <wkv7_chunked_bwd.h>
 #include <wkv7_fwd_v3.h>
-#include <wkv7_bwd_v3.h>
 #include <wkv7_bwd_v5.h>
 #include <wkv7_bwd_v6.h>
 
@@ -21,7 +19,6 @@ constexpr int BWD_V5_MODE = 2 + 4 + 128;
 // same-box A/B on MI355X, B=16 x 2624 x 32 heads: micro-benchmark (random inputs) 1.042 -> 0.993 ms, inside the training step
 // (bench.py, VRWKV_BWD_VARIANT=5 / 6) 0.981 -> 0.872 ms
 constexpr bool BWD_DEFAULT_V6 = true;
-constexpr int BWD_V3_MODE = 2;    // same-process A/B on MI355X (benchmarks/wkv7_ab.py): counters +1..3 % slower, bf16x3 doubling -1 %
 
 inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 
@@ -53,13 +50,13 @@ const char* vrwkv_strerror(int code) {
 }
 
 int vrwkv_wkv7_set_forward_variant(int variant) {
-    if (variant != -1 && variant != 0) return VRWKV_EINVAL;      // -1: chunked MFMA kernel; 0: scalar predecessor
+    if (variant != -1) return VRWKV_EINVAL;                      // one forward generation ships (csrc/wkv7_fwd_v3.h)
     g_fwd_variant = variant;
     return VRWKV_OK;
 }
 
 int vrwkv_wkv7_set_backward_variant(int variant) {
-    if (variant != -1 && variant != 4 && variant != 5 && variant != 6 && !(variant >= 60 && variant < 68)) return VRWKV_EINVAL;   // see include/visualrwkv_hip.h
+    if (variant != -1 && variant != 5 && variant != 6 && !(variant >= 60 && variant < 68)) return VRWKV_EINVAL;   // see include/visualrwkv_hip.h
     g_bwd_variant = variant;
     return VRWKV_OK;
 }
@@ -77,9 +74,7 @@ int vrwkv_wkv7_forward_bf16(int B, int T, int H, const void* w, const void* q, c
     hipStream_t st = (hipStream_t)stream;
     const long heads = (long)B * H;
     const dim3 grid((unsigned)heads);
-    if (g_fwd_variant == 0) {                       // predecessor: one wave per head, scalar recurrence (wkv7_kernels.h)
-        hipLaunchKernelGGL((wkv7::fwd_kernel<16, 8>), grid, dim3(64), 0, st, p);
-    } else {                                        // default: chunked MFMA, producer / consumer waves (wkv7_fwd_v3.h)
+    {                                               // chunked MFMA, producer / consumer waves (wkv7_fwd_v3.h)
         auto kern = &wkv7c::fwd_kernel_v3<false, false, 1>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)sizeof(wkv7c::LdsF));
@@ -123,26 +118,21 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H, const void* w, const void* q, 
                     (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)((long)B * H));
-    if (g_bwd_variant == 4) {                       // predecessor: first producer / consumer schedule (wkv7_bwd_v3.h)
-        auto kern = &wkv7c::bwd_kernel_v3<false, BWD_V3_MODE>;
-        // > 64 KB of LDS needs the opt-in per device: set on every launch (cheap), no per-process flag
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)sizeof(wkv7c::LdsB3));
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kern, grid, dim3(512), sizeof(wkv7c::LdsB3), st, p);
-    } else if (g_bwd_variant == 6 || (g_bwd_variant >= 60 && g_bwd_variant < 68) || (g_bwd_variant == -1 && BWD_DEFAULT_V6)) {
-        // three-stage wave pipeline, 12 waves (wkv7_bwd_v6.h); 60..67: priority / role-placement experiments
+    if (g_bwd_variant == 6 || (g_bwd_variant >= 60 && g_bwd_variant < 68) || (g_bwd_variant == -1 && BWD_DEFAULT_V6)) {
+        // three-stage wave pipeline, 12 waves (wkv7_bwd_v6.h)
         void (*kern)(wkv7::BwdArgs) = &wkv7v6::bwd_kernel_v6<false>;
+#ifdef VRWKV_V6_EXPERIMENTS   // role-timing builds (VRWKV_EXTRA_HIPCC_FLAGS=-DVRWKV_V6_EXPERIMENTS): one or two roles switched off, results garbage
         switch (g_bwd_variant) {
-            case 61: kern = &wkv7v6::bwd_kernel_v6<false, 0, 0, 1, false, true, 1>; break;     // timing experiments: roles switched off
-            case 62: kern = &wkv7v6::bwd_kernel_v6<false, 0, 0, 1, false, true, 2>; break;
-            case 63: kern = &wkv7v6::bwd_kernel_v6<false, 0, 0, 1, false, true, 4>; break;
+            case 61: kern = &wkv7v6::bwd_kernel_v6<false, 0, 0, 1, false, true, 1>; break;     // no P
+            case 62: kern = &wkv7v6::bwd_kernel_v6<false, 0, 0, 1, false, true, 2>; break;     // no I
+            case 63: kern = &wkv7v6::bwd_kernel_v6<false, 0, 0, 1, false, true, 4>; break;     // no J
             case 64: kern = &wkv7v6::bwd_kernel_v6<false, 0, 0, 1, false, true, 3>; break;     // J alone
             case 65: kern = &wkv7v6::bwd_kernel_v6<false, 0, 0, 1, false, true, 5>; break;     // I alone
             case 66: kern = &wkv7v6::bwd_kernel_v6<false, 0, 0, 1, false, true, 6>; break;     // P alone
             case 67: kern = &wkv7v6::bwd_kernel_v6<false, 0, 0, 1, false, true, 7>; break;     // barriers only
             default: break;
         }
+#endif
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)sizeof(wkv7v6::LdsV6));
         if (e != hipSuccess) return (int)e;
