@@ -110,8 +110,29 @@ def main():
     yy = ref.RUN_CUDA_RWKV6(B, T, C, H, r, k, v, w, u)
     gyy = uni(B, T, C)
     yy.backward(gyy)
+    # EXPECTED values of the op section: the reference's own pure-PyTorch recurrence (test_kernel.py:175-215,
+    # run_naive_recurrent_fla, extracted and executed unmodified in fp64 as in make_golden_wkv6.py) on the same inputs,
+    # differentiated by autograd, rounded once to bf16 -- NOT the repository oracle.  What the reference's WKV_6 wrapper
+    # computed above with the oracle behind cpp_extension.load must agree with it (wrapper semantics: ew = -exp(w), per-sample
+    # gu rows summed), which is asserted here at generation time.
+    from make_golden_wkv6 import REF_TEST, _F64, extract_functions
+    fns = extract_functions(REF_TEST, ["naive_recurrent_rwkv6_fla", "run_naive_recurrent_fla"])
+    ns = {"torch": torch, "Optional": __import__("typing").Optional}
+    for name in ("naive_recurrent_rwkv6_fla", "run_naive_recurrent_fla"):
+        exec(compile(fns[name], REF_TEST + ":" + name, "exec"), ns)
+    leaves = [x.detach().double().requires_grad_(True) for x in (r, k, v, w, u)]
+    y64, _ = ns["run_naive_recurrent_fla"](B, T, C, H, *[_F64(x) for x in leaves], None)
+    y64 = y64.as_subclass(torch.Tensor)
+    (y64 * gyy.double()).sum().backward()
+    exp = {"y": y64.detach(), "gr": leaves[0].grad, "gk": leaves[1].grad, "gv": leaves[2].grad, "gw": leaves[3].grad, "gu": leaves[4].grad}
+    got = {"y": yy.detach(), "gr": r.grad, "gk": k.grad, "gv": v.grad, "gw": w.grad, "gu": u.grad}
+    for n_ in exp:
+        e_ = float((got[n_].double() - exp[n_]).norm() / exp[n_].norm())
+        assert e_ < (2e-2 if n_ == "gu" else 6e-3), (n_, e_)      # the wrapper path rounds to bf16 (gu: bf16 rows summed in bf16)
     out["op"] = {"r": r.detach(), "k": k.detach(), "v": v.detach(), "w": w.detach(), "u": u.detach(), "gy": gyy,
-                 "y": yy.detach(), "gr": r.grad, "gk": k.grad, "gv": v.grad, "gw": w.grad, "gu": u.grad}
+                 "provenance": "expected values: VisualRWKV-v6/v6.xx/test_kernel.py:175-215 run_naive_recurrent_fla, fp64 autograd, "
+                               "rounded once to bf16; the WKV_6 wrapper with the repository oracle behind it agrees (checked at generation)",
+                 **{n_: exp[n_].float().bfloat16() for n_ in exp}}
     # ---- VisualRWKV (v6): CLIP tower stand-in of the same class (random tiny config), grid pooling, embedding assembly,
     # bidirectional pass, loss -- all through the reference's own code
     import transformers

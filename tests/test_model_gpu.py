@@ -165,7 +165,9 @@ def test_full_visual_step_matches_an_independent_fp32_cpu_evaluation(monkeypatch
         errs[n] = rel_rms(got.float().cpu(), gr)
         checked += 1
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
-    assert all(e < 4e-2 for e in errs.values()), worst       # observed: worst 2.1e-2 (a token-shift mix parameter); bf16 path vs fp32
+    if os.environ.get("VRWKV_TEST_NOTES") == "1":
+        print("[parity] e2e worst parameter-gradient groups:", [(n, round(e, 4)) for n, e in worst])
+    assert all(e < 2.6e-2 for e in errs.values()), worst     # observed: worst 2.1e-2 (a token-shift mix parameter); bf16 path vs fp32
     assert checked >= 30
     # ---- one optimizer step on both sides (CPU: torch AdamW + clip_grad_norm_; GPU: ZeRO-1 engine, HIP AdamW with the clip
     # factor formed on the device), then the loss again

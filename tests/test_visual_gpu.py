@@ -184,32 +184,31 @@ def test_towers_use_the_patch_embed_kernel(monkeypatch):
 
 def test_sam_vit_b_full_size_product_path(monkeypatch):
     """cfg 5's SAM tower at its real size (1024^2 input, 64 x 64 grid, 14 x 14 windows, global attention over 4096 tokens,
-    12 blocks) through the product path -- patch-embed kernel, rel-pos attention kernel for both window sizes -- against
-    the eager statement of the same module (torch permute + linear, SDPA with the materialised bias) on the same weights."""
-    from visualrwkv_amd import attention as att, fused, hip_attention
+    12 blocks, neck, space-to-depth) through the product path -- patch-embed kernel, rel-pos attention kernel for both window
+    sizes -- against the REFERENCE'S OWN module evaluated in fp32 on the same weights and image
+    (tests/golden/make_golden_sam_full.py: src/sam.py ImageEncoderViT with _build_sam's arguments; weights and input are
+    functions of their names / a seed, the fixture holds 16 384 sampled outputs)."""
+    from tests.golden.det_weights import det_image, det_state
+    from visualrwkv_amd import hip_attention
     from visualrwkv_amd.vit import SamImageEncoder
-    torch.manual_seed(0)
-    m = SamImageEncoder().cuda().bfloat16()
-    with torch.no_grad():
-        for n, p_ in m.named_parameters():
-            if "rel_pos" in n:
-                p_.normal_(0, 0.2)                       # zero-initialised in the reference: make the bias path live
-            p_.requires_grad_(False)
-    x = torch.randn(1, 3, 1024, 1024, device="cuda").bfloat16()
+    ref = torch.load(os.path.join(os.path.dirname(__file__), "golden", "sam_full_ref.pt"))
+    m = SamImageEncoder()
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == ref["param_shapes"]      # same names, same shapes
+    m.load_state_dict(det_state(ref["param_shapes"]), strict=True)
+    m = m.cuda().bfloat16().requires_grad_(False)
+    x = det_image((1, 3, 1024, 1024)).cuda().bfloat16()
     sides = []
     orig = hip_attention.flash_forward_relpos
     monkeypatch.setattr(hip_attention, "flash_forward_relpos", lambda q, k, v, rh, rw, side: (sides.append(side), orig(q, k, v, rh, rw, side))[1])
     with torch.no_grad():
         a = m(x)
-        assert sides.count(64) == 4 and sides.count(14) == 8          # 4 global + 8 windowed blocks ran the HIP kernel
-        att.set_hip_attention(False)
-        monkeypatch.setattr(fused, "patch_embed_supported", lambda *a_, **k_: False)
-        try:
-            b = m(x)
-        finally:
-            att.set_hip_attention(True)
-    assert a.shape == (1, 1024, 32, 32) and torch.isfinite(a.float()).all()     # (B, 4 x 256 channels, 32, 32) after the 2x2 space-to-depth
-    assert rel_rms(a.float(), b.float()) < 2e-2
+    assert sides.count(64) == 4 and sides.count(14) == 8          # 4 global + 8 windowed blocks ran the HIP kernel
+    assert tuple(a.shape) == tuple(ref["out_shape"]) and torch.isfinite(a.float()).all()
+    got = a.float().reshape(-1)[ref["index"].cuda()].cpu()
+    err = rel_rms(got, ref["values"])
+    if os.environ.get("VRWKV_TEST_NOTES") == "1":
+        print(f"[parity] SAM ViT-B full size vs reference fp32: rel_rms {err:.3e}")
+    assert err < 1.8e-2, err                                      # observed 1.2e-2: bf16 weights and activations through 12 blocks vs fp32
 
 
 def _siglip_pair(tr, hidden, heads, inter, image, depth=3):

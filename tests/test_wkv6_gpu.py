@@ -8,6 +8,7 @@ import torch
 
 from oracle.wkv6_oracle import make_inputs6, wkv6_autograd
 from oracle.wkv7_oracle import rel_rms
+from tests.parity import bf16_close
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "v6_ref.pt")
@@ -35,10 +36,12 @@ def test_op_matches_oracle(B, T, H):
     y, (gr, gk, gv, gw, gu) = _run(r, k, v, w, u, gy)
     y_ref, g_ref = wkv6_autograd(r, k, v, w, u, gy)
     C = H * 64
-    assert rel_rms(y.double(), y_ref.reshape(B, T, C)) < 4e-3                 # one bf16 rounding
+    bf16_close(y, y_ref.reshape(B, T, C), f"wkv6 y {B}x{T}x{H}", max_flip=0.02)   # 1e-3 against the bf16-rounded oracle + flips (observed 2.1e-4, 0.5 %)
     for a, ref, n in zip((gr, gk, gv, gw), g_ref[:4], "rkvw"):
-        assert rel_rms(a.double(), ref.reshape(B, T, C)) < 4e-3, n
-    assert rel_rms(gu.double(), g_ref[4]) < 1e-2                               # per-sample bf16 rows summed, as the reference
+        # observed: rel-RMS <= 2.8e-4; 0.2-0.5 % flips, gw up to 6 % (it is a difference of large terms: many exact values
+        # sit within fp32 rounding of a bf16 boundary)
+        bf16_close(a, ref.reshape(B, T, C), f"wkv6 g{n} {B}x{T}x{H}", max_flip=0.10 if n == "w" else 0.02)
+    assert rel_rms(gu.double(), g_ref[4]) < 1e-2                               # per-sample bf16 rows summed in bf16, as the reference (model.py:84)
 
 
 def test_strong_decays_stay_finite():
@@ -47,8 +50,8 @@ def test_strong_decays_stay_finite():
     y, grads = _run(r, k, v, w, u, gy)
     y_ref, g_ref = wkv6_autograd(r, k, v, w, u, gy)
     assert torch.isfinite(y).all() and all(torch.isfinite(g).all() for g in grads)
-    assert rel_rms(y.double(), y_ref.reshape(1, 64, 128)) < 4e-3
-    assert rel_rms(grads[3].double(), g_ref[3].reshape(1, 64, 128)) < 6e-3
+    bf16_close(y, y_ref.reshape(1, 64, 128), "wkv6 strong decays y")
+    bf16_close(grads[3], g_ref[3].reshape(1, 64, 128), "wkv6 strong decays gw", max_flip=0.25)     # observed 2.8e-4, 17 % flips
 
 
 def test_reference_recurrence_fixture():
@@ -60,22 +63,25 @@ def test_reference_recurrence_fixture():
     f = lambda x: x.view(B, T, H, N).bfloat16()
     c = g["zero_state"]
     y, (gr, gk, gv, gw, gu) = _run(f(g["r"]), f(g["k"]), f(g["v"]), f(g["w"]), g["u"].bfloat16(), f(c["gy"]))
-    assert rel_rms(y.double(), c["y"]) < 6e-3
+    bf16_close(y.reshape(c["y"].shape), c["y"], "wkv6 reference recurrence y")
     for a, n in ((gr, "gr"), (gk, "gk"), (gv, "gv"), (gw, "gw")):
-        assert rel_rms(a.double().reshape(c[n].shape), c[n]) < 8e-3, n
+        bf16_close(a.reshape(c[n].shape), c[n], f"wkv6 reference recurrence {n}", max_flip=0.06 if n == "gw" else 0.02)
     assert rel_rms(gu.double(), c["gu"]) < 1.5e-2
 
 
 def test_reference_wrapper_fixture(gold):
+    """RUN_CUDA_RWKV6 on the inputs of the fixture's op section; expected values are the reference's own naive recurrence
+    (test_kernel.py:175-215) in fp64 rounded once to bf16 (tests/golden/make_golden_v6.py; the generator also checks that
+    the reference's WKV_6 wrapper agrees with it)."""
     op = gold["op"]
     B, T, C = op["r"].shape
     H = op["u"].shape[0]
     f = lambda x: x.view(B, T, H, C // H)
     y, (gr, gk, gv, gw, gu) = _run(f(op["r"]), f(op["k"]), f(op["v"]), f(op["w"]), op["u"], f(op["gy"]))
-    assert rel_rms(y.float(), op["y"].float()) < 6e-3                          # both sides rounded to bf16
+    bf16_close(y, op["y"].float(), "wkv6 wrapper fixture y", max_flip=0.02)
     for a, n in ((gr, "gr"), (gk, "gk"), (gv, "gv"), (gw, "gw")):
-        assert rel_rms(a.float(), op[n].float()) < 6e-3, n
-    assert rel_rms(gu.float(), op["gu"].float()) < 1.5e-2
+        bf16_close(a, op[n].float(), f"wkv6 wrapper fixture {n}", max_flip=0.13 if n == "gw" else 0.02)          # gw: observed 1.8e-4 with 8.5 % flips
+    assert rel_rms(gu.float(), op["gu"].float()) < 1.5e-2                      # bf16 per-sample rows summed in bf16 (model.py:84)
 
 
 def test_raw_ops_with_reference_schema():
@@ -92,9 +98,9 @@ def test_raw_ops_with_reference_schema():
     torch.ops.wkv6.backward(B, T, C, H, r, k, v, ew, u, gy, *outs, gu)
     f = lambda x: x.cpu().view(B, T, H, 64)
     y_ref, g_ref = wkv6_autograd(f(r), f(k), f(v), f(w), u.cpu(), f(gy))
-    assert rel_rms(y.cpu().double(), y_ref.reshape(B, T, C)) < 4e-3
-    for a, ref in zip(outs, g_ref[:4]):
-        assert rel_rms(a.cpu().double(), ref.reshape(B, T, C)) < 4e-3
+    bf16_close(y, y_ref.reshape(B, T, C), "wkv6 raw op y")
+    for a, ref, n in zip(outs, g_ref[:4], "rkvw"):
+        bf16_close(a, ref.reshape(B, T, C), f"wkv6 raw op g{n}", max_flip=0.06 if n == "w" else 0.02)
     assert rel_rms(gu.cpu().double().sum(0).view(H, 64), g_ref[4]) < 1e-2
 
 
@@ -111,6 +117,22 @@ def test_op_rejects_bad_arguments():
         wkv6.forward_hip(B, T, 128, H, r, r, r, r.float(), u, torch.empty_like(r))         # C != 64 H
     with pytest.raises(AssertionError):
         wkv6.RUN_CUDA_RWKV6(B, T, 64, H, r.float(), r, r, r, u)
+
+
+def test_config4_full_size_against_oracle():
+    """BASELINE config 4's real operator shape (7B: H = 64 heads, T = 577 + 2048 -> 2624 with the pad), B = 1: one launch at
+    full size; heads are independent, so the pinned oracle (fp64 recurrence, a Python loop over T: 3 minutes for 64 heads)
+    checks four of them -- first, last and two in between -- on forward and all gradients, same 1e-3 + flip-fraction bar."""
+    B, T, H = 1, 2624, 64
+    r, k, v, w, u, gy = make_inputs6(B, T, H, seed=4)
+    y, (gr, gk, gv, gw, gu) = _run(r, k, v, w, u, gy)
+    heads = [0, 21, 42, 63]
+    sel = lambda x: x.view(B, T, H, 64)[:, :, heads].contiguous()
+    y_ref, g_ref = wkv6_autograd(sel(r), sel(k), sel(v), sel(w), u[heads].contiguous(), sel(gy))
+    bf16_close(sel(y), y_ref, "wkv6 cfg4 y")
+    for a, ref, n in zip((gr, gk, gv, gw), g_ref[:4], "rkvw"):
+        bf16_close(sel(a), ref, f"wkv6 cfg4 g{n}", max_flip=0.02)          # observed 1.1-1.6e-4, 0.3-0.8 % flips
+    assert rel_rms(gu.view(H, 64)[heads].double(), g_ref[4]) < 1e-2
 
 
 def test_config4_shape_properties():

@@ -9,9 +9,15 @@ import torch
 
 from oracle import wkv7_c
 from oracle.wkv7_oracle import make_inputs, rel_rms
+from tests.parity import bf16_close
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
+# sequence-parallel paths: the same 1e-3 bar as the sequential kernels plus a bound on the fraction of elements that differ at
+# all.  Observed on MI355X (VRWKV_TEST_NOTES=1 prints them): against the C oracle rel-RMS 1.3-2.1e-4 with 0.3-1.4 % flips for
+# BOTH the sequential and the sequence-parallel path; sequence-parallel against sequential 1e-6 .. 1.2e-4 with <= 0.65 % flips.
+TOL_TPAR = 1e-3
+FLIP_Y, FLIP_G, FLIP_W, FLIP_SEQ = 0.01, 0.012, 0.03, 0.015
 NAMES = ["dw", "dq", "dk", "dv", "dz", "da"]
 
 
@@ -219,10 +225,11 @@ def test_cfg5_shape_fwd_bwd_parity(hip_lib, dev, monkeypatch, tpar):
     y = wkv7.WindBackstepping.apply(*leaves)
     y.backward(dy.to(dev))
     torch.cuda.synchronize()
-    tol = 4e-3 if tpar else TOL      # the segment scan re-associates fp32 state products: isolated 1-ulp bf16 flips
-    assert rel_rms(y.detach().float().cpu(), yr.float()) < tol
+    # both paths against the C oracle (bf16 on both sides): rel-RMS and the fraction of elements that differ at all.  The
+    # segment scan re-associates fp32 state products, which moves isolated roundings, not the bulk of the values.
+    bf16_close(y.detach(), yr.float(), f"cfg5 y tpar={tpar}", tol=TOL_TPAR if tpar else TOL, max_flip=FLIP_Y)
     for n, l, r in zip(NAMES, leaves, ref):
-        assert rel_rms(l.grad.float().cpu(), r.float()) < tol, n
+        bf16_close(l.grad, r.float(), f"cfg5 {n} tpar={tpar}", tol=TOL_TPAR if tpar else TOL, max_flip=FLIP_W if n in ("dw", "dz") else FLIP_G)
 
 
 @pytest.mark.parametrize("B,T,H,P", [(1, 256, 4, 4), (2, 192, 3, 2), (1, 2624, 2, 1)])
@@ -239,8 +246,8 @@ def test_backward_tparallel_equals_sequential(B, T, H, P):
     torch.ops.wind_backstepping.backward(w, q, k, v, z, a, dy, s, sa, *ref)
     got = wkv7.wkv7_backward_tparallel(w, q, k, v, z, a, dy, s, sa, P)
     for name, x, r in zip(("dw", "dq", "dk", "dv", "dz", "da"), got, ref):
-        assert rel_rms(x.float(), r.float()) < 4e-3, name          # bf16 outputs (one ulp = 3.9e-3); the scan re-associates
-                                                                   # the fp32 state products, so some roundings flip
+        # bf16 against bf16 of the sequential kernel: the scan re-associates fp32 state products, so isolated roundings flip
+        bf16_close(x, r.float(), f"tpar-vs-seq {name} {B}x{T}x{H}/{P}", tol=TOL_TPAR, max_flip=FLIP_SEQ)
 
 
 def test_tparallel_training_op_equals_default(monkeypatch):
@@ -263,13 +270,14 @@ def test_tparallel_training_op_equals_default(monkeypatch):
     monkeypatch.setattr(wkv7, "_TPAR_ENV", "1")          # also the forward, which the measured default only cuts for T >= 4096
     got = run()
     for name, x, r in zip(("y", "dw", "dq", "dk", "dv", "dz", "da"), got, ref):
-        assert rel_rms(x.float(), r.float()) < 4e-3, name
+        bf16_close(x, r.float(), f"tpar-op-vs-default {name}", tol=TOL_TPAR, max_flip=FLIP_SEQ)
     y, fin, s, sa = wkv7.wkv7_forward_tparallel(w, q, k, v, z, a, segments=4, train=True)
     y0 = torch.empty_like(v)
     s0 = torch.empty(B, H, T // 16, 64, 64, dtype=torch.float32, device="cuda")
     sa0 = torch.empty(B, T, H, 64, dtype=torch.float32, device="cuda")
     torch.ops.wind_backstepping.forward(w, q, k, v, z, a, y0, s0, sa0)
-    assert rel_rms(s, s0) < 2e-4 and rel_rms(sa, sa0) < 2e-4 and rel_rms(y.float(), y0.float()) < 4e-3
+    assert rel_rms(s, s0) < 2e-4 and rel_rms(sa, sa0) < 2e-4
+    bf16_close(y, y0.float(), "tpar forward y vs sequential", tol=TOL_TPAR, max_flip=FLIP_SEQ)
 
 
 def test_random_shapes_and_input_scales_against_oracle(hip_lib, dev):
