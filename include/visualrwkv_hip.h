@@ -160,7 +160,8 @@ int vrwkv_wkv7_step_bf16(int B, int H, const void* w, const void* q, const void*
                          const void* z, const void* a, float* state, void* y, void* stream);
 
 /* Kernel-generation override for tests and A/B benchmarks; -1 restores the default.
- * forward:  only -1 (csrc/wkv7_fwd_v3.h: chunked MFMA kernel with producer / consumer waves).
+ * forward:  -1 = the default instantiation of csrc/wkv7_fwd_v3.h (chunked MFMA kernel with producer / consumer waves);
+ *            1..5 = other instantiations of the same kernel for A/B (csrc/wkv7_capi.hip).
  * backward: -1 = the default (6), 6 = three-stage wave pipeline of 12 waves (csrc/wkv7_bwd_v6.h), 5 = producer / consumer
  *            schedule of 8 waves (csrc/wkv7_bwd_v5.h; also the sequence-parallel kernel).  Anything else: VRWKV_EINVAL. */
 int vrwkv_wkv7_set_forward_variant(int variant);
@@ -310,6 +311,9 @@ int vrwkv_wgrad_skinny_bf16(long M, int Nw, int D, const void* wide, const void*
 /* Streaming copy dst = src (bytes % 16 == 0): the on-box copy ceiling the WKV roofline fraction is also reported
  * against.  Moves 2 * bytes of HBM traffic. */
 int vrwkv_stream_copy(const void* src, void* dst, long bytes, void* stream);
+/* The same streaming tiling with other read : write mixes (HBM ceilings for a write-heavy / read-heavy kernel): mode 1 fill
+ * (0 : 1), 2 one read + two writes, 3 read only, 4 two reads + one write.  `bytes` = size of one array (multiple of 16). */
+int vrwkv_stream_probe(int mode, const void* a, const void* b, void* d0, void* d1, long bytes, void* stream);
 
 /* out[c][r] = in[r][c] for a row-major (rows, cols) bf16 matrix (rows, cols multiples of 64): the transposed weight copy
  * that lets a Linear's input gradient run in the forward GEMMs' operand layout (replaces the strided torch copy inside

@@ -15,8 +15,9 @@ int emu_wkv7_forward(int B, int T, int H, const void* w, const void* q, const vo
     wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                     (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, s, sa};
     dim3 grid((unsigned)(B * H));
-    (void)variant;
-    emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1>(p); });
+    if (variant == 1) emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1>(p); });                                // round-2 instantiation
+    else if (variant == 2) emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1, 1, false, false, true>(p); });   // no Ab / Kb images
+    else emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1, 1, false, true, true>(p); });                      // default: + tr16 reads
     return 0;
 }
 
@@ -24,7 +25,7 @@ int emu_wkv7_forward_state(int B, int T, int H, const void* w, const void* q, co
                            const void* a, void* y, const float* s0, float* s_final) {
     wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                     (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, nullptr, nullptr, nullptr, s0, s_final};
-    emu::launch(dim3((unsigned)(B * H)), dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1>(p); });
+    emu::launch(dim3((unsigned)(B * H)), dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1, 1, false, true, true>(p); });
     return 0;
 }
 
@@ -89,6 +90,6 @@ extern "C" int emu_wkv7_forward_state_train(int B, int T, int H, const void* w, 
                                             float* s_ckpt, float* sa) {
     wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                     (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, s_ckpt, sa, nullptr, s0, s_final};
-    emu::launch(dim3((unsigned)(B * H)), dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1>(p); });
+    emu::launch(dim3((unsigned)(B * H)), dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1, 1, false, true, true>(p); });
     return 0;
 }

@@ -135,6 +135,53 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const u32x4_t* __restr
     }
 }
 
+// Streaming probes with other read : write mixes than the copy's 1 : 1 (the WKV7 forward writes 22 of its 34 B/element, the
+// backward reads 34 of its 46): mode 1 = fill (0 : 1), 2 = one read, two writes (1 : 2), 3 = read only (1 : 0; a value that
+// cannot occur keeps the loads alive), 4 = two reads, one write (2 : 1).  Same tiling as the copy kernel.
+template <int MODE>
+__global__ __launch_bounds__(256) void stream_mix_kernel(const u32x4_t* __restrict__ a, const u32x4_t* __restrict__ b, u32x4_t* __restrict__ d0,
+                                                         u32x4_t* __restrict__ d1, long nvec) {
+    constexpr int U = 8;
+    const long ntiles = (nvec + 256 * U - 1) / (256 * U);
+    u32x4_t keep = {0u, 0u, 0u, 0u};
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long base = t * 256 * U + threadIdx.x;
+        u32x4_t v[U], w[U];
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            if (base + q * 256 >= nvec) continue;
+            if (MODE != 1) v[q] = __builtin_nontemporal_load(a + base + q * 256); else v[q] = keep;
+            if (MODE == 4) w[q] = __builtin_nontemporal_load(b + base + q * 256);
+        }
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            if (base + q * 256 >= nvec) continue;
+            if (MODE == 4) v[q] ^= w[q];
+            if (MODE == 3) { keep |= v[q]; continue; }
+            __builtin_nontemporal_store(v[q], d0 + base + q * 256);
+            if (MODE == 2) __builtin_nontemporal_store(v[q], d1 + base + q * 256);
+        }
+    }
+    if (MODE == 3 && keep[0] == 0x12345678u && keep[1] == 0x9abcdef0u) d0[0] = keep;
+}
+
+// bytes = size of ONE array; returns 0 / error.  a, b: sources; d0, d1: destinations (unused ones may alias).
+extern "C" int vrwkv_stream_probe(int mode, const void* a, const void* b, void* d0, void* d1, long bytes, void* stream) {
+    if (!a || !d0 || bytes <= 0 || bytes % 16 != 0) return VRWKV_EINVAL;
+    const dim3 grid(256 * 8), block(256);
+    const long nvec = bytes / 16;
+    hipStream_t st = (hipStream_t)stream;
+    switch (mode) {
+        case 1: hipLaunchKernelGGL(stream_mix_kernel<1>, grid, block, 0, st, (const u32x4_t*)a, (const u32x4_t*)b, (u32x4_t*)d0, (u32x4_t*)d1, nvec); break;
+        case 2: hipLaunchKernelGGL(stream_mix_kernel<2>, grid, block, 0, st, (const u32x4_t*)a, (const u32x4_t*)b, (u32x4_t*)d0, (u32x4_t*)d1, nvec); break;
+        case 3: hipLaunchKernelGGL(stream_mix_kernel<3>, grid, block, 0, st, (const u32x4_t*)a, (const u32x4_t*)b, (u32x4_t*)d0, (u32x4_t*)d1, nvec); break;
+        case 4: hipLaunchKernelGGL(stream_mix_kernel<4>, grid, block, 0, st, (const u32x4_t*)a, (const u32x4_t*)b, (u32x4_t*)d0, (u32x4_t*)d1, nvec); break;
+        default: return VRWKV_EINVAL;
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? VRWKV_OK : (int)e;
+}
+
 extern "C" int vrwkv_stream_copy(const void* src, void* dst, long bytes, void* stream) {
     if (!src || !dst || bytes <= 0) return VRWKV_EINVAL;
     if (bytes % 16 != 0) return VRWKV_ESHAPE;

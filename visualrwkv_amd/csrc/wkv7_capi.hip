@@ -16,6 +16,11 @@ int g_bwd_variant = -1;
 // T chain on the bf16 matrix core (2) + producer priority 2 (4; same-box A/B: 1.18 -> 1.09 ms) + priorities swapped in
 // segment 1, where the producers have ~1.2k cycles of slack per chunk and the consumers none (128; 1.09 -> 1.04 ms)
 constexpr int BWD_V5_MODE = 2 + 4 + 128;
+// Forward default: no Ab / Kb images (state update from Ah / Kh, scaled by c_L afterwards; T chain splitting every matrix once
+// per level) + natural [t][j] images read with ds_read_b64_tr_b16.  Same-box A/B (benchmarks/wkv7_ab.py --fwd 1 2 4): B=8
+// 0.358 -> 0.331 -> 0.324 ms, B=16 0.647 -> 0.637 -> 0.627 ms.  Variant 1 = the round-2 instantiation.
+#define VRWKV_FWD_DEFAULT wkv7c::fwd_kernel_v3<false, false, 1, 1, false, true, true>
+#define VRWKV_FWD_DEFAULT_PROF wkv7c::fwd_kernel_v3<true, false, 1, 1, false, true, true>
 // same-box A/B on MI355X, B=16 x 2624 x 32 heads: micro-benchmark (random inputs) 1.042 -> 0.993 ms, inside the training step
 // (bench.py, VRWKV_BWD_VARIANT=5 / 6) 0.981 -> 0.872 ms
 constexpr bool BWD_DEFAULT_V6 = true;
@@ -50,7 +55,7 @@ const char* vrwkv_strerror(int code) {
 }
 
 int vrwkv_wkv7_set_forward_variant(int variant) {
-    if (variant != -1) return VRWKV_EINVAL;                      // one forward generation ships (csrc/wkv7_fwd_v3.h)
+    if (variant != -1 && !(variant >= 1 && variant <= 5)) return VRWKV_EINVAL;   // 1..5: A/B instantiations of the same kernel
     g_fwd_variant = variant;
     return VRWKV_OK;
 }
@@ -75,7 +80,12 @@ int vrwkv_wkv7_forward_bf16(int B, int T, int H, const void* w, const void* q, c
     const long heads = (long)B * H;
     const dim3 grid((unsigned)heads);
     {                                               // chunked MFMA, producer / consumer waves (wkv7_fwd_v3.h)
-        auto kern = &wkv7c::fwd_kernel_v3<false, false, 1>;
+        void (*kern)(wkv7::FwdArgs) = &VRWKV_FWD_DEFAULT;
+        if (g_fwd_variant == 1) kern = &wkv7c::fwd_kernel_v3<false, false, 1>;
+        if (g_fwd_variant == 2) kern = &wkv7c::fwd_kernel_v3<false, false, 1, 1, false, false, true>;
+        if (g_fwd_variant == 3) kern = &wkv7c::fwd_kernel_v3<false, true, 1, 1, false, false, true>;     // + 16-byte transposed stores
+        if (g_fwd_variant == 4) kern = &wkv7c::fwd_kernel_v3<false, false, 1, 1, false, true, true>;     // + natural images read with tr16
+        if (g_fwd_variant == 5) kern = &wkv7c::fwd_kernel_v3<false, false, 1, 2, false, false, true>;     // + two chunks of prefetch
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)sizeof(wkv7c::LdsF));
         if (e != hipSuccess) return (int)e;
@@ -95,7 +105,7 @@ int vrwkv_wkv7_forward_state_bf16(int B, int T, int H, const void* w, const void
         return VRWKV_EALIGN;
     wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                     (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, s_ckpt, sa, nullptr, s0, s_final};
-    auto kern = &wkv7c::fwd_kernel_v3<false, false, 1>;
+    auto kern = &VRWKV_FWD_DEFAULT;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)sizeof(wkv7c::LdsF));
     if (e != hipSuccess) return (int)e;
@@ -186,10 +196,10 @@ int vrwkv_wkv7_profile_bf16(int backward, int B, int T, int H, const void* w, co
     if (!backward) {
         wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                         (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, s, sa, dbg};
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7c::fwd_kernel_v3<true, false, 1>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&VRWKV_FWD_DEFAULT_PROF),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsF));
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((wkv7c::fwd_kernel_v3<true, false, 1>), grid, dim3(512), sizeof(wkv7c::LdsF), st, p);
+        hipLaunchKernelGGL((VRWKV_FWD_DEFAULT_PROF), grid, dim3(512), sizeof(wkv7c::LdsF), st, p);
     } else if (backward == 2) {                     // three-stage pipeline (wkv7_bwd_v6.h): I / J / P wave 0, five stamps each
         wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                         (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,

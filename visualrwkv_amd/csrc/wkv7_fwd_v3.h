@@ -64,6 +64,13 @@ DEVFN f32x4 regmm_bf16x3(f32x4 pt, f32x4 qc) {
     const f32x4 acc = mfma_16x16x32_bf16(mk8(ph, ph), mk8(qh, ql), zero4());
     return mfma_16x16x32_bf16(mk8(pl.x, pl.y, 0u, 0u), mk8(qh.x, qh.y, 0u, 0u), acc);
 }
+// regmm_bf16x3 with the operands already split (a level of the doubling uses every matrix twice)
+struct SplitF { uint2 h, l; };
+DEVFN SplitF splitf(f32x4 x) { SplitF s; split4(x, s.h, s.l); return s; }
+DEVFN f32x4 regmm_pre(const SplitF& p_, const SplitF& q_) {
+    const f32x4 acc = mfma_16x16x32_bf16(mk8(p_.h, p_.h), mk8(q_.h, q_.l), zero4());
+    return mfma_16x16x32_bf16(mk8(p_.l.x, p_.l.y, 0u, 0u), mk8(q_.h.x, q_.h.y, 0u, 0u), acc);
+}
 // acc += M[row c16][s] * B[s][col] with M an fp32 [t][s] image in LDS and B a C-layout fragment
 DEVFN f32x4 mm_f32_image(f32x4 acc, const float (*M)[SF], int c16, int g, f32x4 bfrag) {
     const float4 m = *reinterpret_cast<const float4*>(&M[c16][4 * g]);
@@ -74,7 +81,7 @@ DEVFN f32x4 mm_f32_image(f32x4 acc, const float (*M)[SF], int c16, int g, f32x4 
     return acc;
 }
 
-template <bool SFX, bool TRD = false>
+template <bool SFX, bool TRD = false, bool NOAB = false>
 DEVFN void prep_v3(BufF& B, const RawChunk& rc, int pw, int lane) {
     const int t = lane & 15, g = lane >> 4, j0 = 16 * pw + 4 * g;
     float wr[4], q[4], k[4], z[4], a[4];
@@ -85,15 +92,16 @@ DEVFN void prep_v3(BufF& B, const RawChunk& rc, int pw, int lane) {
         const float lw = -fast_exp(wr[e]);
         float x = lw;
         x += dpp_shr<1>(x); x += dpp_shr<2>(x); x += dpp_shr<4>(x); x += dpp_shr<8>(x);
-        float rest;                                    // sum of log-decays of the later tokens of the chunk
-        if (SFX) {                                     // exclusive suffix scan with DPP row shifts (no LDS round trip)
+        float rest = 0.f;                              // sum of log-decays of the later tokens of the chunk
+        if (NOAB) {                                    // no Ab / Kb at all: the state update uses Ah / Kh and scales by c_L afterwards
+        } else if (SFX) {                                     // exclusive suffix scan with DPP row shifts (no LDS round trip)
             float y = lw;
             y += dpp_shl<1>(y); y += dpp_shl<2>(y); y += dpp_shl<4>(y); y += dpp_shl<8>(y);
             rest = y - lw;
         } else {
             rest = lane_bcast(x, (lane & 48) | 15) - x;
         }
-        const float c = fast_exp(x), cp = fast_exp(x - lw), ic = fast_exp(-x), cb = fast_exp(rest);
+        const float c = fast_exp(x), cp = fast_exp(x - lw), ic = fast_exp(-x), cb = NOAB ? 0.f : fast_exp(rest);
         zt[e] = z[e] * cp; qt[e] = q[e] * c; ah[e] = a[e] * ic; kh[e] = k[e] * ic;
         ab[e] = a[e] * cb; kb[e] = k[e] * cb; cend[e] = c;
     }
@@ -102,24 +110,28 @@ DEVFN void prep_v3(BufF& B, const RawChunk& rc, int pw, int lane) {
     split4(qt, h, l); st8(&B.opnd[2][t][j0], h); st8(&B.opnd[3][t][j0], l);
     split4(ah, h, l); st8(&B.opnd[4][t][j0], h); st8(&B.opnd[5][t][j0], l);
     split4(kh, h, l); st8(&B.opnd[6][t][j0], h); st8(&B.opnd[7][t][j0], l);
+    uint2 abh, abl, kbh, kbl;                          // the operands of the state update whose k index is the token
+    if (NOAB) {                                        // Ah / Kh once more (their split is already done): S_L = diag(c_L)(S0 + Ah^T SA + Kh^T V)
+        split4(ah, abh, abl); split4(kh, kbh, kbl);    // (common sub-expressions of the two splits above)
+    } else {
+        split4(ab, abh, abl); split4(kb, kbh, kbl);
+    }
     if (TRD) {
-        split4(ab, h, l); st8(&B.abn[0][t][j0], h); st8(&B.abn[1][t][j0], l);
-        split4(kb, h, l); st8(&B.abn[2][t][j0], h); st8(&B.abn[3][t][j0], l);
+        st8(&B.abn[0][t][j0], abh); st8(&B.abn[1][t][j0], abl);
+        st8(&B.abn[2][t][j0], kbh); st8(&B.abn[3][t][j0], kbl);
         st8(&B.vn[t][j0], rc.v);
     } else {
-        split4(ab, h, l);
-        B.trn[0][j0 + 0][t] = (uint16_t)h.x; B.trn[0][j0 + 1][t] = (uint16_t)(h.x >> 16);
-        B.trn[0][j0 + 2][t] = (uint16_t)h.y; B.trn[0][j0 + 3][t] = (uint16_t)(h.y >> 16);
-        B.trn[1][j0 + 0][t] = (uint16_t)l.x; B.trn[1][j0 + 1][t] = (uint16_t)(l.x >> 16);
-        B.trn[1][j0 + 2][t] = (uint16_t)l.y; B.trn[1][j0 + 3][t] = (uint16_t)(l.y >> 16);
-        split4(kb, h, l);
-        B.trn[2][j0 + 0][t] = (uint16_t)h.x; B.trn[2][j0 + 1][t] = (uint16_t)(h.x >> 16);
-        B.trn[2][j0 + 2][t] = (uint16_t)h.y; B.trn[2][j0 + 3][t] = (uint16_t)(h.y >> 16);
-        B.trn[3][j0 + 0][t] = (uint16_t)l.x; B.trn[3][j0 + 1][t] = (uint16_t)(l.x >> 16);
-        B.trn[3][j0 + 2][t] = (uint16_t)l.y; B.trn[3][j0 + 3][t] = (uint16_t)(l.y >> 16);
+        B.trn[0][j0 + 0][t] = (uint16_t)abh.x; B.trn[0][j0 + 1][t] = (uint16_t)(abh.x >> 16);
+        B.trn[0][j0 + 2][t] = (uint16_t)abh.y; B.trn[0][j0 + 3][t] = (uint16_t)(abh.y >> 16);
+        B.trn[1][j0 + 0][t] = (uint16_t)abl.x; B.trn[1][j0 + 1][t] = (uint16_t)(abl.x >> 16);
+        B.trn[1][j0 + 2][t] = (uint16_t)abl.y; B.trn[1][j0 + 3][t] = (uint16_t)(abl.y >> 16);
+        B.trn[2][j0 + 0][t] = (uint16_t)kbh.x; B.trn[2][j0 + 1][t] = (uint16_t)(kbh.x >> 16);
+        B.trn[2][j0 + 2][t] = (uint16_t)kbh.y; B.trn[2][j0 + 3][t] = (uint16_t)(kbh.y >> 16);
+        B.trn[3][j0 + 0][t] = (uint16_t)kbl.x; B.trn[3][j0 + 1][t] = (uint16_t)(kbl.x >> 16);
+        B.trn[3][j0 + 2][t] = (uint16_t)kbl.y; B.trn[3][j0 + 3][t] = (uint16_t)(kbl.y >> 16);
         B.vt[j0 + 0][t] = (uint16_t)rc.v.x; B.vt[j0 + 1][t] = (uint16_t)(rc.v.x >> 16);
         B.vt[j0 + 2][t] = (uint16_t)rc.v.y; B.vt[j0 + 3][t] = (uint16_t)(rc.v.y >> 16);
-}
+    }
     if (t == 15) *reinterpret_cast<float4*>(&B.cl[j0]) = make_float4(cend[0], cend[1], cend[2], cend[3]);
 }
 
@@ -140,6 +152,7 @@ DEVFN f32x4 score_v3(const BufF& B, int mx, int my, int c16, int g) {
     return a0;
 }
 
+template <bool SHARED_SPLIT = false>
 DEVFN void scores_v3(BufF& B, int pw, int lane) {
     const int c16 = lane & 15, g = lane >> 4;
     if (pw == 1 || pw == 3) {                 // transposed scores against Kh: lane (g, c16 = t), reg r <-> s = 4g+r
@@ -176,6 +189,22 @@ DEVFN void scores_v3(BufF& B, int pw, int lane) {
         wave_lds_fence();
 #pragma unroll
         for (int r = 0; r < 4; ++r) TT[r] = XT[r] + ((4 * g + r == c16) ? 1.f : 0.f);
+        if (SHARED_SPLIT) {                    // every matrix of a level is split once (4 splits instead of 6 per level)
+            SplitF sx = splitf(X), sxt = splitf(XT);
+#pragma unroll
+            for (int level = 0; level < 3; ++level) {
+                const f32x4 X2 = regmm_pre(sxt, sx);
+                f32x4 XT2 = XT;
+                if (level < 2) XT2 = regmm_pre(sx, sxt);
+                const SplitF sx2 = splitf(X2);
+                const f32x4 D = regmm_pre(sx2, splitf(TT));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) TT[r] += D[r];
+                X = X2; XT = XT2;
+                sx = sx2;
+                if (level < 2) sxt = splitf(XT2);
+            }
+        } else {
 #pragma unroll
         for (int level = 0; level < 3; ++level) {
             const f32x4 X2 = regmm_bf16x3(XT, X);
@@ -186,13 +215,15 @@ DEVFN void scores_v3(BufF& B, int pw, int lane) {
             for (int r = 0; r < 4; ++r) TT[r] += D[r];
             X = X2; XT = XT2;
         }
+        }
         *reinterpret_cast<float4*>(&B.scf[1][c16][4 * g]) = make_float4(TT[0], TT[1], TT[2], TT[3]);   // T[c16][4g+r]
     }
 }
 
 // PF: chunks of input prefetch held in registers by the producers (HBM latency under load exceeds one chunk time);
 // SFX: decay suffix by DPP scan instead of ds_bpermute.
-template <bool PROF, bool WIDE = true, int PRIO = 1, int PF = 1, bool SFX = false, bool TRD = false>
+// NOAB: no Ab / Kb images (the state update multiplies by c_L afterwards) and a T chain that splits every matrix once per level.
+template <bool PROF, bool WIDE = true, int PRIO = 1, int PF = 1, bool SFX = false, bool TRD = false, bool NOAB = false>
 __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
     LdsF& lds = *reinterpret_cast<LdsF*>(dyn_lds());
     const int T = p.T, H = p.H;
@@ -228,7 +259,7 @@ __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
                     rc = rc2;
                     if (c + 2 < nchunk) fetch(rc2, c + 2);
                 } else if (c + 1 < nchunk) fetch(rc, c + 1);
-                prep_v3<SFX, TRD>(lds.b[c & 1], cur, pw, lane);
+                prep_v3<SFX, TRD, NOAB>(lds.b[c & 1], cur, pw, lane);
                 lds_flag_add(&lds.prep_done);
             }
             WKV_STAMP(0)
@@ -236,7 +267,7 @@ __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
             // not s_barrier): the consumers' second half does not depend on anything produced in this iteration.
             if (c < nchunk) lds_flag_wait(&lds.prep_done, 4u * (unsigned)(c + 1));
             WKV_STAMP(1)
-            if (c < nchunk) scores_v3(lds.b[c & 1], pw, lane);
+            if (c < nchunk) scores_v3<NOAB>(lds.b[c & 1], pw, lane);
             WKV_STAMP(2)
             block_sync_lds();                           // B
             WKV_STAMP(3)
@@ -339,7 +370,7 @@ __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
         for (int jb = 0; jb < 4; ++jb) {
             const float4 cl = *reinterpret_cast<const float4*>(&B.cl[16 * jb + 4 * g]);
             f32x4 acc = S[jb];
-            acc[0] *= cl.x; acc[1] *= cl.y; acc[2] *= cl.z; acc[3] *= cl.w;
+            if (!NOAB) { acc[0] *= cl.x; acc[1] *= cl.y; acc[2] *= cl.z; acc[3] *= cl.w; }
             const int j = 16 * jb + c16;
             bf16x8 ah, al;
             if (TRD) {
@@ -353,6 +384,7 @@ __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
             acc = mfma_16x16x32_bf16(ah, b1, acc);
             acc = mfma_16x16x32_bf16(ah, b2, acc);
             acc = mfma_16x16x32_bf16(al, b1, acc);
+            if (NOAB) { acc[0] *= cl.x; acc[1] *= cl.y; acc[2] *= cl.z; acc[3] *= cl.w; }      // S_L = diag(c_L)(S0 + Ah^T SA + Kh^T V)
             S[jb] = acc;
             if (p.s) {
                 if (WIDE) {

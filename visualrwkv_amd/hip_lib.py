@@ -69,6 +69,7 @@ PROTOTYPES = {
     "vrwkv_wgrad_skinny_ws_floats": (_c_long, [_c_long, _c_int, _c_int]),
     "vrwkv_wgrad_skinny_bf16": (_c_int, [_c_long, _c_int, _c_int] + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 2),
     "vrwkv_stream_copy":(_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p]),
+    "vrwkv_stream_probe": (_c_int, [_c_int] + [_c_void_p] * 4 + [_c_long, _c_void_p]),
     "vrwkv_transpose_bf16": (_c_int, [_c_long, _c_long, _c_void_p, _c_void_p, _c_void_p]),
     "vrwkv_resize_normalize_u8": (_c_int, [_c_int, _c_int, _c_void_p, _c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                            _c_void_p, _c_int, _c_void_p]),
