@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grad-cp", type=int, default=0)
+    ap.add_argument("--fused", type=int, default=1, help="fused RWKV-6 glue kernels (ddmix, gn_silu, add+LN, loss)")
     a = ap.parse_args()
     import transformers
     from visualrwkv_amd import build, wkv6
@@ -35,7 +36,7 @@ def main():
     C = a.n_embd
     args = SimpleNamespace(n_embd=C, dim_att=C, n_layer=a.layers, head_size_a=64, head_size_divisor=8,
                            dim_ffn=int((C * 3.5) // 32 * 32), vocab_size=65536, dropout=0, grad_cp=a.grad_cp, ctx_len=4096,
-                           load_model="", grid_size=-1)
+                           load_model="", grid_size=-1, fused=bool(a.fused))
     clip_cfg = transformers.CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24,
                                              num_attention_heads=16, image_size=336, patch_size=14)
     torch.manual_seed(42)
@@ -81,7 +82,7 @@ def main():
     n_par = sum(p.numel() for p in model.rwkv.parameters())
     print(json.dumps({"config": "cfg4: VisualRWKV-6 %dL C%d + CLIP ViT-L/14-336" % (a.layers, C), "lm_params_B": round(n_par / 1e9, 2),
                       "micro_bsz": B, "seq_len": T, "tokens_per_s": round(B * T / dt), "ms_per_step": round(dt * 1e3, 1),
-                      "losses": [round(x, 3) for x in losses], "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1), "grad_cp": a.grad_cp}))
+                      "losses": [round(x, 3) for x in losses], "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1), "grad_cp": a.grad_cp, "fused": bool(a.fused)}))
 
 
 if __name__ == "__main__":

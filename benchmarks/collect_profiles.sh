@@ -1,9 +1,13 @@
 #!/bin/bash
 # Round evidence, run on the GPU box from the repo root:  bash benchmarks/collect_profiles.sh <tag>
-TAG=${1:-r2}; R=$PWD; O=$R/gpurun_out/$TAG; mkdir -p $O
+TAG=${1:-r3}; R=$PWD; O=$R/gpurun_out/$TAG; mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/pytest_gpu.txt
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 >> $O/pytest_gpu.txt
 timeout 600 python bench.py --steps 5 --warmup 2 2>&1 | grep -v amdgpu.ids | tail -1 > $O/bench.json
+timeout 600 python bench.py --steps 5 --warmup 2 --data loader --no-cpu-baseline --no-grad-cp-companion 2>&1 | grep -v amdgpu.ids | tail -1 > $O/bench_loader.json
+# the bench line and the rocprofv3 kernel statistics of the SAME process + clock / power state + the DVFS probe
+bash benchmarks/roofline_evidence.sh $TAG > $O/roofline_evidence_summary.json 2>&1
+timeout 300 python benchmarks/hbm_mix_probe.py 2>&1 | grep -v amdgpu | tail -1 > $O/hbm_mix_probe.json
 cd /tmp; export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/step -o step -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/step.log 2>&1
 # matrix-core utilisation per kernel of the same step (counters in their own pass: no --stats, no other trace domain)
@@ -17,6 +21,8 @@ cp profiles/wkv7_pmc.json $O/wkv7_pmc.json
 VRWKV_FORCE_COLLECTIVES=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
     bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | grep -v amdgpu.ids | tail -1 > $O/bench_rccl_1rank.json
 python benchmarks/wkv7_phases.py 8 2>&1 | tail -1 > $O/wkv7_phases_b8.json
+python benchmarks/wkv7_phases.py 16 2>&1 | tail -1 > $O/wkv7_phases_b16.json
+python benchmarks/wkv7_ab.py --B 8 16 --fwd 1 -1 --bwd 5 6 --rounds 4 2>&1 | grep -v amdgpu > $O/wkv7_ab.jsonl
 python benchmarks/wkv7_micro.py --B 8 16 32 --iters 20 2>&1 | grep -v amdgpu > $O/wkv7_micro.jsonl
 # stateful generation: decode step (B = 1, 4), per-kernel breakdown of the captured step, prompt ingestion
 python benchmarks/decode_micro.py 64 1 2>&1 | grep -v amdgpu | tail -1 > $O/decode_micro.jsonl

@@ -192,6 +192,15 @@ int vrwkv_mix_bwd_bf16(long ntok, int T, int C, int M, const void* x, const void
  * LoRA (src/model.py:178,182); the two gradients are summed in the kernel instead of by autograd's element-wise add */
 int vrwkv_mix_bwd2_bf16(long ntok, int T, int C, int M, const void* x, const void* const* mu, const void* const* dout,
                         const void* dout3_second, void* dx, float* dmu, float* ws, void* stream);
+/* RWKV-6 (BASELINE config 4) glue, same conventions:  ddmix = token shift with per-token lerp weights, 5 outputs
+ * (VisualRWKV-v6/v6.0/src/model.py:150-160: out_j = x + (x[t-1] - x) (mu_j + mm_j), mm_j (ntok, C) bf16 from the 5-way LoRA);
+ * gn_silu = GroupNorm(C/64 groups, eps)(y) * silu(gg) (model.py:166,176-184).  mix accepts M = 1, 2 (RWKV_CMix_x060) and 6. */
+int vrwkv_ddmix_fwd_bf16(long ntok, int T, int C, const void* x, const void* const* mu, const void* const* mm, void* const* out, void* stream);
+int vrwkv_ddmix_bwd_bf16(long ntok, int T, int C, const void* x, const void* const* mu, const void* const* mm, const void* const* dout,
+                         void* dx, void* const* dmm, float* dmu /* 5*C */, float* ws, void* stream);
+int vrwkv_gn_silu_fwd_bf16(long ntok, int C, float eps, const void* y, const void* gg, const void* ln_w, const void* ln_b, void* out, void* stream);
+int vrwkv_gn_silu_bwd_bf16(long ntok, int C, float eps, const void* y, const void* gg, const void* ln_w, const void* ln_b, const void* dout,
+                           void* dy, void* dgg, float* dparams /* 2*C: dln_w dln_b */, float* ws, void* stream);
 int vrwkv_decay_fwd_bf16(long ntok, int C, const void* h, const void* w0, void* w, void* stream);
 int vrwkv_decay_bwd_bf16(long ntok, int C, const void* h, const void* w0, const void* dw, void* dh, float* dw0, float* ws,
                          void* stream);

@@ -7,6 +7,8 @@ import pytest
 import torch
 
 from oracle.wkv6_oracle import make_inputs6, wkv6_autograd
+import torch.nn as nn
+
 from oracle.wkv7_oracle import rel_rms
 from tests.parity import bf16_close
 
@@ -167,3 +169,82 @@ def test_tmix_x060_against_reference_module(gold):
     named = dict(m.named_parameters())
     for k, gr in gold["tmix_grads_bf16"].items():
         assert rel_rms(named[k].grad.float().cpu(), gr.float()) < 3e-2, k
+
+
+def _v6_args(fused):
+    return SimpleNamespace(n_embd=256, dim_att=256, n_layer=4, head_size_a=64, head_size_divisor=8, dim_ffn=896, dropout=0, grad_cp=0,
+                           vocab_size=512, fused=fused)
+
+
+def test_fused_x060_glue_matches_eager_modules():
+    """The fused RWKV-6 glue (one-pass lerp, 5-way data-dependent lerp, GroupNorm * silu(gate), two-lerp channel-mix, sigmoid
+    gate; csrc/tmix_fused.hip ddmix / gn_silu) against the eager statement of the SAME modules on the GPU (model.py:146-226):
+    outputs, input gradient and every parameter gradient of RWKV_Tmix_x060 and RWKV_CMix_x060."""
+    from visualrwkv_amd.rwkv6 import RWKV_CMix_x060, RWKV_Tmix_x060
+    torch.manual_seed(3)
+    for cls in (RWKV_Tmix_x060, RWKV_CMix_x060):
+        ref = cls(_v6_args(False), 1)
+        with torch.no_grad():
+            for p in ref.parameters():
+                if float(p.abs().sum()) == 0.0:
+                    p.normal_(0, 0.05)
+        ref = ref.bfloat16().cuda()
+        fus = cls(_v6_args(True), 1).bfloat16().cuda()
+        fus.load_state_dict(ref.state_dict())
+        x = (torch.randn(2, 48, 256, device="cuda") * 0.7).bfloat16()
+        gy = torch.randn(2, 48, 256, device="cuda").bfloat16()
+        outs = []
+        for m in (ref, fus):
+            xi = x.clone().requires_grad_(True)
+            y = m(xi)
+            y.backward(gy)
+            outs.append((y.detach(), xi.grad, {n: p.grad for n, p in m.named_parameters()}))
+        (y0, gx0, g0), (y1, gx1, g1) = outs
+        assert rel_rms(y1.float(), y0.float()) < 1e-2, cls.__name__                 # two bf16 pipelines, different rounding points
+        assert rel_rms(gx1.float(), gx0.float()) < 2e-2, cls.__name__
+        for n in g0:
+            assert g1[n] is not None, n
+            assert rel_rms(g1[n].float(), g0[n].float()) < 3e-2, (cls.__name__, n)
+
+
+def test_ddmix_and_gn_silu_kernels_against_fp32():
+    """The two new RWKV-6 kernels against their fp32 statements rounded once (outputs, all gradients), token-shift indexing
+    bit-exact at the sequence starts."""
+    from visualrwkv_amd import fused
+    torch.manual_seed(5)
+    B, T, C = 3, 37, 128
+    x = torch.randn(B, T, C, device="cuda").bfloat16().requires_grad_(True)
+    mm = (torch.randn(5, B, T, C, device="cuda") * 0.2).bfloat16().requires_grad_(True)
+    mus = [torch.rand(1, 1, C, device="cuda").bfloat16().requires_grad_(True) for _ in range(5)]
+    outs = fused.ddmix(x, mm, *mus)
+    gs = [torch.randn(B, T, C, device="cuda").bfloat16() for _ in range(5)]
+    torch.autograd.backward(outs, gs)
+    got = [o.detach() for o in outs], x.grad.clone(), mm.grad.clone(), [m.grad.clone() for m in mus]
+    xf, mmf, musf = x.detach().float().requires_grad_(True), mm.detach().float().requires_grad_(True), [m.detach().float().requires_grad_(True) for m in mus]
+    xx = torch.nn.functional.pad(xf, (0, 0, 1, -1)) - xf
+    ref = [xf + xx * (musf[j] + mmf[j]) for j in range(5)]
+    torch.autograd.backward(ref, [g.float() for g in gs])
+    for j in range(5):
+        assert rel_rms(got[0][j].float(), ref[j].detach().bfloat16().float()) < 1e-3, j
+        assert torch.equal(got[0][j][:, 0].float(), (xf[:, 0] * (1 - (musf[j][0, 0] + mmf[j][:, 0]))).detach().bfloat16().float())   # shift sees zeros at t = 0
+        assert rel_rms(got[3][j].float(), musf[j].grad) < 5e-3, j
+    assert rel_rms(got[1].float(), xf.grad) < 3e-3 and rel_rms(got[2].float(), mmf.grad) < 3e-3
+    # GroupNorm * silu(gate)
+    ln = nn.GroupNorm(C // 64, C, eps=64e-5).cuda()
+    with torch.no_grad():
+        ln.weight.normal_(1, 0.2); ln.bias.normal_(0, 0.2)
+    lnb = nn.GroupNorm(C // 64, C, eps=64e-5).cuda().bfloat16()
+    lnb.load_state_dict(ln.state_dict())
+    y = torch.randn(B * T, C, device="cuda").bfloat16().requires_grad_(True)
+    gg = torch.randn(B * T, C, device="cuda").bfloat16().requires_grad_(True)
+    out = fused.gn_silu(y, gg, lnb.weight, lnb.bias, lnb.eps)
+    go = torch.randn(B * T, C, device="cuda").bfloat16()
+    out.backward(go)
+    yf, ggf = y.detach().float().requires_grad_(True), gg.detach().float().requires_grad_(True)
+    lnf = nn.GroupNorm(C // 64, C, eps=64e-5).cuda()
+    lnf.load_state_dict({k: v.float() for k, v in lnb.state_dict().items()})
+    reff = lnf(yf) * torch.nn.functional.silu(ggf)
+    reff.backward(go.float())
+    assert rel_rms(out.detach().float(), reff.detach().bfloat16().float()) < 1e-3
+    assert rel_rms(y.grad.float(), yf.grad) < 3e-3 and rel_rms(gg.grad.float(), ggf.grad) < 3e-3
+    assert rel_rms(lnb.weight.grad.float(), lnf.weight.grad) < 5e-3 and rel_rms(lnb.bias.grad.float(), lnf.bias.grad) < 5e-3

@@ -71,9 +71,11 @@ struct Ptrs6 { const uint16_t* p[MAXM]; };
 struct MPtrs6 { uint16_t* p[MAXM]; };
 
 // ---------------------------------------------------------------------------------------------- F1 / F5: shift + lerps
-template <int M>
+// DD (RWKV-6, VisualRWKV-v6/v6.0/src/model.py:150-160): the lerp weight of output j is mu_j + mm_j[n] with a per-token
+// tensor mm_j (the 5-way data-dependent LoRA of the time-mix) instead of the channel vector alone.
+template <int M, bool DD = false>
 __global__ void mix_fwd_kernel(long ntok, int T, int C, const uint16_t* __restrict__ x, const uint16_t* __restrict__ x_prev,
-                               Ptrs6 mu, MPtrs6 out) {
+                               Ptrs6 mu, MPtrs6 out, Ptrs6 mm = Ptrs6{}) {
     const int c0 = threadIdx.x * 8;
     V8 m[M];
 #pragma unroll
@@ -96,9 +98,14 @@ __global__ void mix_fwd_kernel(long ntok, int T, int C, const uint16_t* __restri
         }
 #pragma unroll
         for (int j = 0; j < M; ++j) {
-            V8 o;
+            V8 o, w = m[j];
+            if (DD) {
+                const V8 t = ld8f(mm.p[j] + n * C + c0);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o.f[e] = fmaf(xx.f[e], m[j].f[e], xv.f[e]);
+                for (int e = 0; e < 8; ++e) w.f[e] += t.f[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.f[e] = fmaf(xx.f[e], w.f[e], xv.f[e]);
             st8f(out.p[j] + n * C + c0, o);
         }
     }
@@ -123,10 +130,11 @@ DEVFN void st4f(uint16_t* p, const V4& v) {
 }
 // DUP3: output 3 (x_v of the time-mix) has two consumers (value projection, v-gate LoRA); their gradients arrive as
 // dout.p[3] and dout3b and are summed here instead of by a separate element-wise kernel (3 x 172 MB per layer).
-template <int M, bool DUP3>
+// DD: per-token lerp weights mu_j + mm_j[n]; additionally writes dmm_j[n] = d_j[n] (x[n-1] - x[n]).
+template <int M, bool DUP3, bool DD = false>
 __global__ __launch_bounds__(512) void mix_bwd_kernel(long ntok, int T, int C, const uint16_t* __restrict__ x, Ptrs6 mu, Ptrs6 dout,
                                                       const uint16_t* __restrict__ dout3b, uint16_t* __restrict__ dx,
-                                                      float* __restrict__ dmu) {
+                                                      float* __restrict__ dmu, Ptrs6 mm = Ptrs6{}, MPtrs6 dmm = MPtrs6{}) {
     const long lo = ntok * blockIdx.x / gridDim.x, hi = ntok * (blockIdx.x + 1) / gridDim.x;
     for (int c0 = threadIdx.x * 4; c0 < C; c0 += blockDim.x * 4) {
         V4 m[M], gm[M];
@@ -161,9 +169,16 @@ __global__ __launch_bounds__(512) void mix_bwd_kernel(long ntok, int T, int C, c
 #pragma unroll
             for (int e = 0; e < 4; ++e) { dsum.f[e] = 0.f; bv.f[e] = 0.f; }
 #pragma unroll
-            for (int j = 0; j < M; ++j)
+            for (int j = 0; j < M; ++j) {
+                V4 w = m[j];
+                if (DD) {
+                    const V4 t = ld4f(mm.p[j] + n * C + c0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { dsum.f[e] += d[j].f[e]; bv.f[e] = fmaf(d[j].f[e], m[j].f[e], bv.f[e]); }
+                    for (int e = 0; e < 4; ++e) w.f[e] += t.f[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { dsum.f[e] += d[j].f[e]; bv.f[e] = fmaf(d[j].f[e], w.f[e], bv.f[e]); }
+            }
             if (n > lo) {
                 V4 o;
 #pragma unroll
@@ -171,13 +186,24 @@ __global__ __launch_bounds__(512) void mix_bwd_kernel(long ntok, int T, int C, c
                 st4f(dx + (n - 1) * C + c0, o);
             }
             if (inside) {
+                V4 xxv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float xx = (cont ? xprev.f[e] : 0.f) - xv.f[e];
+                    xxv.f[e] = xx;
 #pragma unroll
                     for (int j = 0; j < M; ++j) gm[j].f[e] = fmaf(d[j].f[e], xx, gm[j].f[e]);
                     aprev.f[e] = dsum.f[e] - bv.f[e];
                     xprev.f[e] = xv.f[e];
+                }
+                if (DD) {
+#pragma unroll
+                    for (int j = 0; j < M; ++j) {
+                        V4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o.f[e] = d[j].f[e] * xxv.f[e];
+                        st4f(dmm.p[j] + n * C + c0, o);
+                    }
                 }
             }
         }
@@ -376,6 +402,70 @@ __global__ void post_fwd_kernel(PostFwd p) {
         st8f(p.out + o, out);
     }
 }
+// RWKV-6 (VisualRWKV-v6/v6.0/src/model.py:176-184, jit_func_2 and the silu of :166): out = GroupNorm(H, C, eps)(y) * silu(gg)
+__global__ void gn_silu_fwd_kernel(long ntok, int C, float eps, const uint16_t* __restrict__ yp, const uint16_t* __restrict__ ggp,
+                                   const uint16_t* __restrict__ ln_w, const uint16_t* __restrict__ ln_b, uint16_t* __restrict__ outp) {
+    const int c0 = threadIdx.x * 8;
+    const V8 lw = ld8f(ln_w + c0), lb = ld8f(ln_b + c0);
+    for (long nb = (long)blockIdx.x * TPB; nb < ntok; nb += (long)gridDim.x * TPB)
+    for (long n = nb; n < nb + TPB && n < ntok; ++n) {
+        const long o = n * C + c0;
+        const V8 y = ld8f(yp + o), gg = ld8f(ggp + o);
+        float s1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1 += y.f[e];
+        const float mean = group_sum<3>(s1) * (1.f / 64.f);
+        float s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = y.f[e] - mean; s2 = fmaf(d, d, s2); }
+        const float rstd = fast_rsqrt(group_sum<3>(s2) * (1.f / 64.f) + eps);
+        V8 out;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out.f[e] = ((y.f[e] - mean) * rstd * lw.f[e] + lb.f[e]) * (gg.f[e] * sigmoidf_(gg.f[e]));
+        st8f(outp + o, out);
+    }
+}
+__global__ void gn_silu_bwd_kernel(long ntok, int C, float eps, const uint16_t* __restrict__ yp, const uint16_t* __restrict__ ggp,
+                                   const uint16_t* __restrict__ ln_w, const uint16_t* __restrict__ ln_b, const uint16_t* __restrict__ doutp,
+                                   uint16_t* __restrict__ dyp, uint16_t* __restrict__ dggp, float* __restrict__ part) {
+    const int c0 = threadIdx.x * 8;
+    const V8 lw = ld8f(ln_w + c0), lb = ld8f(ln_b + c0);
+    V8 g_w = zero8(), g_b = zero8();
+    for (long n = range_lo(ntok), hi = range_hi(ntok); n < hi; ++n) {
+        const long o = n * C + c0;
+        const V8 y = ld8f(yp + o), gg = ld8f(ggp + o), d = ld8f(doutp + o);
+        float s1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1 += y.f[e];
+        const float mean = group_sum<3>(s1) * (1.f / 64.f);
+        float s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float dd = y.f[e] - mean; s2 = fmaf(dd, dd, s2); }
+        const float rstd = fast_rsqrt(group_sum<3>(s2) * (1.f / 64.f) + eps);
+        V8 yn, dyn, dgg;
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            yn.f[e] = (y.f[e] - mean) * rstd;
+            const float gn = yn.f[e] * lw.f[e] + lb.f[e];
+            const float sg = sigmoidf_(gg.f[e]), silu = gg.f[e] * sg;
+            dgg.f[e] = d.f[e] * gn * (sg * (1.f + gg.f[e] * (1.f - sg)));      // d silu / d gg
+            const float dt = d.f[e] * silu;
+            g_w.f[e] = fmaf(dt, yn.f[e], g_w.f[e]);
+            g_b.f[e] += dt;
+            dyn.f[e] = dt * lw.f[e];
+            m1 += dyn.f[e];
+            m2 = fmaf(dyn.f[e], yn.f[e], m2);
+        }
+        m1 = group_sum<3>(m1) * (1.f / 64.f); m2 = group_sum<3>(m2) * (1.f / 64.f);
+        V8 dy;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dy.f[e] = rstd * (dyn.f[e] - m1 - yn.f[e] * m2);
+        st8f(dyp + o, dy); st8f(dggp + o, dgg);
+    }
+    put_partial(part, 2, 0, C, c0, g_w); put_partial(part, 2, 1, C, c0, g_b);
+}
+
 struct PostBwd {
     long ntok; int C; float eps;
     const uint16_t *y, *r, *k, *v, *g, *ln_w, *ln_b, *r_k, *dout;
@@ -469,13 +559,14 @@ int vrwkv_mix_fwd_bf16(long ntok, int T, int C, int M, const void* x, const void
 
 int vrwkv_mix_fwd_prev_bf16(long ntok, int T, int C, int M, const void* x, const void* x_prev, const void* const* mu,
                             void* const* out, void* stream) {
-    if (ntok <= 0 || T <= 0 || !x || !mu || !out || (M != 1 && M != 6)) return VRWKV_EINVAL;
+    if (ntok <= 0 || T <= 0 || !x || !mu || !out || (M != 1 && M != 2 && M != 6)) return VRWKV_EINVAL;
     if (!ok_c(C) || ntok % T != 0) return VRWKV_ESHAPE;
     Ptrs6 m{}; MPtrs6 o{};
     for (int i = 0; i < M; ++i) { m.p[i] = (const uint16_t*)mu[i]; o.p[i] = (uint16_t*)out[i]; if (!m.p[i] || !o.p[i]) return VRWKV_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
-    if (M == 6) hipLaunchKernelGGL(mix_fwd_kernel<6>, tok_grid(ntok), dim3(C / 8), 0, st, ntok, T, C, (const uint16_t*)x, (const uint16_t*)x_prev, m, o);
-    else hipLaunchKernelGGL(mix_fwd_kernel<1>, tok_grid(ntok), dim3(C / 8), 0, st, ntok, T, C, (const uint16_t*)x, (const uint16_t*)x_prev, m, o);
+    if (M == 6) hipLaunchKernelGGL(mix_fwd_kernel<6>, tok_grid(ntok), dim3(C / 8), 0, st, ntok, T, C, (const uint16_t*)x, (const uint16_t*)x_prev, m, o, Ptrs6{});
+    else if (M == 2) hipLaunchKernelGGL(mix_fwd_kernel<2>, tok_grid(ntok), dim3(C / 8), 0, st, ntok, T, C, (const uint16_t*)x, (const uint16_t*)x_prev, m, o, Ptrs6{});
+    else hipLaunchKernelGGL(mix_fwd_kernel<1>, tok_grid(ntok), dim3(C / 8), 0, st, ntok, T, C, (const uint16_t*)x, (const uint16_t*)x_prev, m, o, Ptrs6{});
     return done();
 }
 
@@ -488,7 +579,7 @@ int vrwkv_mix_bwd_bf16(long ntok, int T, int C, int M, const void* x, const void
 
 int vrwkv_mix_bwd2_bf16(long ntok, int T, int C, int M, const void* x, const void* const* mu, const void* const* dout,
                         const void* dout3_second, void* dx, float* dmu, float* ws, void* stream) {
-    if (ntok <= 0 || T <= 0 || !x || !mu || !dout || !dx || !dmu || !ws || (M != 1 && M != 6)) return VRWKV_EINVAL;
+    if (ntok <= 0 || T <= 0 || !x || !mu || !dout || !dx || !dmu || !ws || (M != 1 && M != 2 && M != 6)) return VRWKV_EINVAL;
     if (dout3_second && M != 6) return VRWKV_EINVAL;
     if (!ok_c(C) || ntok % T != 0) return VRWKV_ESHAPE;
     Ptrs6 m{}, d{};
@@ -497,10 +588,63 @@ int vrwkv_mix_bwd2_bf16(long ntok, int T, int C, int M, const void* x, const voi
     const int G = bwd_grid(ntok);
     const int threads = C / 4 < 512 ? C / 4 : 512;
     const uint16_t* d2 = (const uint16_t*)dout3_second;
-    if (M == 6 && d2) hipLaunchKernelGGL((mix_bwd_kernel<6, true>), dim3(G), dim3(threads), 0, st, ntok, T, C, (const uint16_t*)x, m, d, d2, (uint16_t*)dx, ws);
-    else if (M == 6) hipLaunchKernelGGL((mix_bwd_kernel<6, false>), dim3(G), dim3(threads), 0, st, ntok, T, C, (const uint16_t*)x, m, d, d2, (uint16_t*)dx, ws);
-    else hipLaunchKernelGGL((mix_bwd_kernel<1, false>), dim3(G), dim3(threads), 0, st, ntok, T, C, (const uint16_t*)x, m, d, d2, (uint16_t*)dx, ws);
+    if (M == 6 && d2) hipLaunchKernelGGL((mix_bwd_kernel<6, true>), dim3(G), dim3(threads), 0, st, ntok, T, C, (const uint16_t*)x, m, d, d2, (uint16_t*)dx, ws, Ptrs6{}, MPtrs6{});
+    else if (M == 6) hipLaunchKernelGGL((mix_bwd_kernel<6, false>), dim3(G), dim3(threads), 0, st, ntok, T, C, (const uint16_t*)x, m, d, d2, (uint16_t*)dx, ws, Ptrs6{}, MPtrs6{});
+    else if (M == 2) hipLaunchKernelGGL((mix_bwd_kernel<2, false>), dim3(G), dim3(threads), 0, st, ntok, T, C, (const uint16_t*)x, m, d, d2, (uint16_t*)dx, ws, Ptrs6{}, MPtrs6{});
+    else hipLaunchKernelGGL((mix_bwd_kernel<1, false>), dim3(G), dim3(threads), 0, st, ntok, T, C, (const uint16_t*)x, m, d, d2, (uint16_t*)dx, ws, Ptrs6{}, MPtrs6{});
     colsum(G, (long)M * C, ws, dmu, st);
+    return done();
+}
+
+// RWKV-6 data-dependent token shift (VisualRWKV-v6/v6.0/src/model.py:150-160): out_j = x + (x[t-1] - x) (mu_j + mm_j), j < 5.
+int vrwkv_ddmix_fwd_bf16(long ntok, int T, int C, const void* x, const void* const* mu, const void* const* mm, void* const* out, void* stream) {
+    if (ntok <= 0 || T <= 0 || !x || !mu || !mm || !out) return VRWKV_EINVAL;
+    if (!ok_c(C) || ntok % T != 0) return VRWKV_ESHAPE;
+    Ptrs6 m{}, t{}; MPtrs6 o{};
+    for (int i = 0; i < 5; ++i) {
+        m.p[i] = (const uint16_t*)mu[i]; t.p[i] = (const uint16_t*)mm[i]; o.p[i] = (uint16_t*)out[i];
+        if (!m.p[i] || !t.p[i] || !o.p[i]) return VRWKV_EINVAL;
+    }
+    hipLaunchKernelGGL((mix_fwd_kernel<5, true>), tok_grid(ntok), dim3(C / 8), 0, (hipStream_t)stream, ntok, T, C, (const uint16_t*)x,
+                       (const uint16_t*)nullptr, m, o, t);
+    return done();
+}
+// backward: dx, dmm_j (ntok, C) bf16 each, dmu = 5*C floats; ws: vrwkv_param_grad_ws_floats(ntok, C, 5)
+int vrwkv_ddmix_bwd_bf16(long ntok, int T, int C, const void* x, const void* const* mu, const void* const* mm, const void* const* dout,
+                         void* dx, void* const* dmm, float* dmu, float* ws, void* stream) {
+    if (ntok <= 0 || T <= 0 || !x || !mu || !mm || !dout || !dx || !dmm || !dmu || !ws) return VRWKV_EINVAL;
+    if (!ok_c(C) || ntok % T != 0) return VRWKV_ESHAPE;
+    Ptrs6 m{}, t{}, d{}; MPtrs6 o{};
+    for (int i = 0; i < 5; ++i) {
+        m.p[i] = (const uint16_t*)mu[i]; t.p[i] = (const uint16_t*)mm[i]; d.p[i] = (const uint16_t*)dout[i]; o.p[i] = (uint16_t*)dmm[i];
+        if (!m.p[i] || !t.p[i] || !d.p[i] || !o.p[i]) return VRWKV_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int G = bwd_grid(ntok);
+    const int threads = C / 4 < 512 ? C / 4 : 512;
+    hipLaunchKernelGGL((mix_bwd_kernel<5, false, true>), dim3(G), dim3(threads), 0, st, ntok, T, C, (const uint16_t*)x, m, d, (const uint16_t*)nullptr,
+                       (uint16_t*)dx, ws, t, o);
+    colsum(G, 5L * C, ws, dmu, st);
+    return done();
+}
+
+// RWKV-6 output stage: out = GroupNorm(C/64 groups, eps)(y) * silu(gg)   (model.py:166,176-184)
+int vrwkv_gn_silu_fwd_bf16(long ntok, int C, float eps, const void* y, const void* gg, const void* ln_w, const void* ln_b, void* out, void* stream) {
+    if (ntok <= 0 || !y || !gg || !ln_w || !ln_b || !out) return VRWKV_EINVAL;
+    if (!ok_c(C)) return VRWKV_ESHAPE;
+    hipLaunchKernelGGL(gn_silu_fwd_kernel, tok_grid(ntok), dim3(C / 8), 0, (hipStream_t)stream, ntok, C, eps, (const uint16_t*)y, (const uint16_t*)gg,
+                       (const uint16_t*)ln_w, (const uint16_t*)ln_b, (uint16_t*)out);
+    return done();
+}
+// dparams = [dln_w | dln_b] (2 C floats); ws: vrwkv_param_grad_ws_floats(ntok, C, 2)
+int vrwkv_gn_silu_bwd_bf16(long ntok, int C, float eps, const void* y, const void* gg, const void* ln_w, const void* ln_b, const void* dout,
+                           void* dy, void* dgg, float* dparams, float* ws, void* stream) {
+    if (ntok <= 0 || !y || !gg || !ln_w || !ln_b || !dout || !dy || !dgg || !dparams || !ws) return VRWKV_EINVAL;
+    if (!ok_c(C)) return VRWKV_ESHAPE;
+    const int G = bwd_grid(ntok);
+    hipLaunchKernelGGL(gn_silu_bwd_kernel, dim3(G), dim3(C / 8), 0, (hipStream_t)stream, ntok, C, eps, (const uint16_t*)y, (const uint16_t*)gg,
+                       (const uint16_t*)ln_w, (const uint16_t*)ln_b, (const uint16_t*)dout, (uint16_t*)dy, (uint16_t*)dgg, ws);
+    colsum(G, 2L * C, ws, dparams, (hipStream_t)stream);
     return done();
 }
 

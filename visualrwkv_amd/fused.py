@@ -477,6 +477,137 @@ def ce_supported(logits):
     return logits.is_cuda and logits.dtype == torch.bfloat16 and logits.dim() == 3 and logits.shape[-1] % 8 == 0
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# RWKV-6 glue (BASELINE config 4; VisualRWKV-v6/v6.0/src/model.py:146-194, 213-226)
+# ---------------------------------------------------------------------------------------------------------------
+class _DDMix(torch.autograd.Function):
+    """RWKV-6's data-dependent token shift: out_j = x + (shift(x) - x) * (mu_j + mm_j), j < 5, mm_j (B,T,C) per token."""
+
+    @staticmethod
+    def forward(ctx, x, mm, *mus):
+        B, T, C = x.shape
+        x = x.contiguous()
+        mm = mm.contiguous()                                # (5, B, T, C)
+        mus_c = [m.reshape(C).contiguous() for m in mus]
+        _chk(x, mm, *mus_c)
+        assert len(mus) == 5 and tuple(mm.shape) == (5, B, T, C)
+        outs = [torch.empty_like(x) for _ in range(5)]
+        rc = hip_lib.load().vrwkv_ddmix_fwd_bf16(B * T, T, C, x.data_ptr(), _ptr_array(mus_c), _ptr_array(list(mm.unbind(0))),
+                                                 _ptr_array(outs), _stream(x))
+        hip_lib.check(rc, "vrwkv_ddmix_fwd_bf16")
+        ctx.save_for_backward(x, mm, *mus_c)
+        ctx.mu_shapes = [m.shape for m in mus]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        x, mm, *mus_c = ctx.saved_tensors
+        B, T, C = x.shape
+        douts = [d.contiguous() for d in douts]
+        _chk(*douts)
+        dx = torch.empty_like(x)
+        dmm = torch.empty_like(mm)
+        dmu = torch.empty(5, C, dtype=torch.float32, device=x.device)
+        ws = _ws(B * T, C, 5, x.device)
+        rc = hip_lib.load().vrwkv_ddmix_bwd_bf16(B * T, T, C, x.data_ptr(), _ptr_array(mus_c), _ptr_array(list(mm.unbind(0))),
+                                                 _ptr_array(douts), dx.data_ptr(), _ptr_array(list(dmm.unbind(0))), dmu.data_ptr(),
+                                                 ws.data_ptr(), _stream(x))
+        hip_lib.check(rc, "vrwkv_ddmix_bwd_bf16")
+        dmu = dmu.to(x.dtype)
+        return (dx, dmm, *[dmu[i].view(s) for i, s in enumerate(ctx.mu_shapes)])
+
+
+class _GnSilu(torch.autograd.Function):
+    """out = GroupNorm(C/64 groups)(y) * silu(gg)   (RWKV_Tmix_x060.jit_func_2 with the silu of jit_func)"""
+
+    @staticmethod
+    def forward(ctx, y, gg, ln_w, ln_b, eps):
+        y, gg = y.contiguous(), gg.contiguous()
+        C = y.shape[-1]
+        lw, lb = ln_w.contiguous(), ln_b.contiguous()
+        _chk(y, gg, lw, lb)
+        out = torch.empty_like(y)
+        rc = hip_lib.load().vrwkv_gn_silu_fwd_bf16(y.numel() // C, C, float(eps), y.data_ptr(), gg.data_ptr(), lw.data_ptr(), lb.data_ptr(),
+                                                   out.data_ptr(), _stream(y))
+        hip_lib.check(rc, "vrwkv_gn_silu_fwd_bf16")
+        ctx.save_for_backward(y, gg, lw, lb)
+        ctx.eps = float(eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, gg, lw, lb = ctx.saved_tensors
+        dout = dout.contiguous()
+        _chk(dout)
+        C = y.shape[-1]
+        dy, dgg = torch.empty_like(y), torch.empty_like(gg)
+        pg = torch.empty(2, C, dtype=torch.float32, device=y.device)
+        ws = _ws(y.numel() // C, C, 2, y.device)
+        rc = hip_lib.load().vrwkv_gn_silu_bwd_bf16(y.numel() // C, C, ctx.eps, y.data_ptr(), gg.data_ptr(), lw.data_ptr(), lb.data_ptr(),
+                                                   dout.data_ptr(), dy.data_ptr(), dgg.data_ptr(), pg.data_ptr(), ws.data_ptr(), _stream(y))
+        hip_lib.check(rc, "vrwkv_gn_silu_bwd_bf16")
+        pgb = pg.to(y.dtype)
+        return dy, dgg, pgb[0], pgb[1], None
+
+
+ddmix = _DDMix.apply
+gn_silu = _GnSilu.apply
+
+
+def supported6(x):
+    """bf16 CUDA activations with C a multiple of 64 (the glue kernels' 8-channel lanes and 64-channel heads)."""
+    return x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 64 == 0 and x.shape[-1] <= 8192
+
+
+def tmix6_forward(m, x, wkv=None):
+    """RWKV_Tmix_x060.forward (VisualRWKV-v6/v6.0/src/model.py:146-194) with the glue fused: one kernel for the first lerp
+    (xxx), one for the five data-dependent lerps, the T,N input-gradient layout for the projections, GroupNorm * silu(gate)
+    in one pass.  `m` is the module (parameter names as in the reference)."""
+    from . import wkv6 as _wkv6
+    B, T, C = x.shape
+    mm_ = lora_mm if torch.is_grad_enabled() and LORA_WGRAD else torch.matmul
+    (xxx,) = mix(x, m.time_maa_x)
+    h = torch.tanh(mm_(xxx, m.time_maa_w1)).view(B * T, 5, -1).transpose(0, 1)
+    mm5 = torch.bmm(h, m.time_maa_w2).view(5, B, T, C)
+    xw, xk, xv, xr, xg = ddmix(x, mm5, m.time_maa_w, m.time_maa_k, m.time_maa_v, m.time_maa_r, m.time_maa_g)
+    r = linear(m.receptance, xr)
+    k = linear(m.key, xk)
+    v = linear(m.value, xv)
+    gg = linear(m.gate, xg)
+    w = m.time_decay + mm_(torch.tanh(mm_(xw, m.time_decay_w1)), m.time_decay_w2)
+    run = wkv if wkv is not None else _wkv6.RUN_CUDA_RWKV6
+    y = run(B, T, C, m.n_head, r, k, v, w, m.time_faaaa)
+    y = gn_silu(y.reshape(B * T, C), gg.reshape(B * T, C), m.ln_x.weight, m.ln_x.bias, m.ln_x.eps).view(B, T, C)
+    return linear(m.output, y)
+
+
+def cmix6_forward(m, x):
+    """RWKV_CMix_x060.forward (model.py:213-226): two lerps in one pass, relu^2, sigmoid(receptance) * value in one pass."""
+    xk, xr = mix(x, m.time_maa_k, m.time_maa_r)
+    kv = linear(m.value, relu_sq(linear(m.key, xk)))
+    return gate(kv, linear(m.receptance, xr))
+
+
+def blocks6_forward(rwkv, x, wkv=None, grad_cp=False):
+    """RWKV-6 Blocks + ln_out with the residual adds fused into the LayerNorms (model.py:233-258,300-325)."""
+    x = rwkv.blocks[0].ln0(x)
+    delta = None
+
+    def seg(block, x, delta):
+        x, h = add_ln(x, delta, block.ln1)
+        x, h = add_ln(x, tmix6_forward(block.att, h, wkv), block.ln2)
+        return x, cmix6_forward(block.ffn, h)
+
+    for block in rwkv.blocks:
+        if grad_cp:
+            from torch.utils.checkpoint import checkpoint
+            x, delta = checkpoint(seg, block, x, delta, use_reentrant=False)
+        else:
+            x, delta = seg(block, x, delta)
+    _, h = add_ln(x, delta, rwkv.ln_out)
+    return h
+
+
 def tmix_forward(m, x, v_first):
     """RWKV_Tmix_x070.forward (src/model.py:163-195) with the glue fused; `m` is the module."""
     B, T, C = x.shape

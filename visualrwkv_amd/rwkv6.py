@@ -82,6 +82,10 @@ class RWKV_Tmix_x060(nn.Module):
 
     def forward(self, x, wkv=None):
         B, T, C = x.size()
+        if getattr(self.args, "fused", False):
+            from . import fused
+            if fused.supported6(x) and self.receptance.weight.dtype == torch.bfloat16:
+                return fused.tmix6_forward(self, x, wkv)
         r, k, v, g, w = self.mix(x)
         run = wkv if wkv is not None else _wkv6.RUN_CUDA_RWKV6
         y = run(B, T, C, self.n_head, r, k, v, w, self.time_faaaa)
@@ -107,6 +111,10 @@ class RWKV_CMix_x060(nn.Module):
         self.value = nn.Linear(args.dim_ffn, C, bias=False)
 
     def forward(self, x):
+        if getattr(self.args, "fused", False):
+            from . import fused
+            if fused.supported6(x) and self.key.weight.dtype == torch.bfloat16:
+                return fused.cmix6_forward(self, x)
         xx = time_shift(x) - x
         xk = x + xx * self.time_maa_k
         xr = x + xx * self.time_maa_r
@@ -134,6 +142,12 @@ class Block(nn.Module):
     def forward(self, x, wkv=None):
         if self.layer_id == 0:
             x = self.ln0(x)
+        if getattr(self.args, "fused", False) and self.args.dropout == 0:
+            from . import fused
+            if fused.supported6(x) and fused.add_ln_supported(x) and self.ln1.weight.dtype == torch.bfloat16:
+                _, h = fused.add_ln(x, None, self.ln1)                         # LayerNorm kernel; the attention's residual add is
+                x, h = fused.add_ln(x, self.att(h, wkv), self.ln2)            # fused with ln2 (csrc/ln_fused.hip)
+                return x + self.ffn(h)
         x = x + self.att(self.ln1(x), wkv)
         x = x + self.ffn(self.ln2(x))
         return x
@@ -156,6 +170,11 @@ class RWKV(nn.Module):
         args = self.args
         if args.dropout > 0:
             x = self.drop0(x)
+        if getattr(args, "fused", False) and args.dropout == 0:
+            from . import fused
+            if fused.supported6(x) and fused.add_ln_supported(x) and self.head.weight.dtype == torch.bfloat16:
+                h = fused.blocks6_forward(self, x, wkv, grad_cp=args.grad_cp == 1 and torch.is_grad_enabled())
+                return fused.linear(self.head, h)
         for block in self.blocks:
             if args.grad_cp == 1 and torch.is_grad_enabled():
                 from torch.utils.checkpoint import checkpoint

@@ -61,10 +61,17 @@ class VisualRWKV6(nn.Module):
                 x = block(x, wkv)
             if rev:
                 x = torch.cat((x[:, :s], x[:, s:e].flip(1), x[:, e:]), dim=1)
+        if getattr(args, "fused", False) and x.is_cuda and self.rwkv.head.weight.dtype == torch.bfloat16:
+            from . import fused
+            return fused.linear(self.rwkv.head, self.rwkv.ln_out(x))           # input gradient in the forward GEMMs' layout
         return self.rwkv.head(self.rwkv.ln_out(x))
 
     def training_step(self, batch, batch_idx=0, wkv=None):
         logits, targets = self(batch, wkv)
+        if getattr(self.args, "fused", False):
+            from . import fused
+            if fused.ce_supported(logits):                                      # one-pass shifted CE + L2Wrap (csrc/loss_fused.hip)
+                return fused.loss_from_logits(logits, targets, IGNORE_INDEX)
         shift_logits = logits[..., :-1, :].contiguous()
         shift_labels = targets[..., 1:].contiguous()
         valid = torch.max((shift_labels != IGNORE_INDEX).sum(1), torch.ones_like(shift_labels[:, 0]))
