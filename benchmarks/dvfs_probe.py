@@ -55,16 +55,18 @@ def run(B=16, T=2624, H=32, iters=20):
             return best
         fwd()
         rec = {"fwd_ms": round(t(fwd), 4), "bwd_ms": round(t(bwd), 4)}
-        # shader clock during the backward: profiling build, cycles of workgroup 0's consumer wave / its life in 10 ns ticks
-        dbg = torch.zeros(16, dtype=torch.int64, device=dev)
+        # shader clock during the backward (profiling build of the SAME kernel generation, wkv7_bwd_v6.h): cycles of workgroup 0's
+        # I wave 0 over its life / that life in 10 ns ticks of the constant 100 MHz counter
+        dbg = torch.zeros(32, dtype=torch.int64, device=dev)
         for _ in range(3):
             dbg.zero_()
-            assert lib.vrwkv_wkv7_profile_bf16(1, B, T, H, *[t_.data_ptr() for t_ in (w, q, k, v, z, a, dy, y, s, sa, *g)], dbg.data_ptr(), st) == 0
+            assert lib.vrwkv_wkv7_profile_bf16(2, B, T, H, *[t_.data_ptr() for t_ in (w, q, k, v, z, a, dy, y, s, sa, *g)], dbg.data_ptr(), st) == 0
             torch.cuda.synchronize()
         d = dbg.cpu().tolist()
-        if d[7] > 0:
-            rec["bwd_shader_clock_GHz"] = round(sum(d[:7]) / (d[7] * 10.0), 3)
-            rec["bwd_cycles_per_chunk_wg0"] = round(sum(d[:7]) / (T // 16))
+        if d[15] > 0:
+            cyc = sum(d[0:5]) + d[18] + d[19]
+            rec["bwd_shader_clock_GHz"] = round(cyc / (d[15] * 10.0), 3)
+            rec["bwd_cycles_per_step_wg0"] = round(cyc / (T // 16 + 3))
         out["cases"][name] = rec
     out["smi_after"] = smi()
     return out

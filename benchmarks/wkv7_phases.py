@@ -33,8 +33,9 @@ def run(B=8, T=2624, H=32, bwd_variant=-1, fwd_variant=-1):
         out[key] = {n: round(d[i] / nch) for i, n in enumerate(names)}
         out[key + "_total_per_chunk"] = round(sum(d[:15]) / nch)
         if bw == 2 and d[15] > 0:
-            out["bwd_v6_shader_clock_GHz"] = round(sum(d[0:5]) / (d[15] * 10.0), 3)
-            out["bwd_v6_cycles_per_chunk"] = round(sum(d[0:5]) / nch)
+            cyc = sum(d[0:5]) + d[18] + d[19]            # I wave 0: the five role stamps + the two inner i-split stamps
+            out["bwd_v6_shader_clock_GHz"] = round(cyc / (d[15] * 10.0), 3)
+            out["bwd_v6_cycles_per_step"] = round(cyc / (nch + 3))
         if bw == 1 and d[7] > 0:      # shader clock while this kernel runs: consumer-wave cycles of workgroup 0 / its life on the 100 MHz counter
             out["bwd_shader_clock_GHz"] = round(sum(d[:7]) / (d[7] * 10.0), 3)
     return out

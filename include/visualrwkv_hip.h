@@ -97,6 +97,10 @@ int vrwkv_add_ln_fwd_bf16(long ntok, int C, float eps, const void* x, const void
                           void* xn, void* y, float* mean, float* rstd, void* stream);
 int vrwkv_add_ln_bwd_bf16(long ntok, int C, const void* dy, const void* dres, const void* xn, const float* mean,
                           const float* rstd, const void* w, void* dx, float* dwb, float* ws, void* stream);
+/* Inference form for the frozen ViT towers: xn = x + delta * dscale (dscale = LayerScale gamma (C) bf16 or NULL; delta NULL: no
+ * add, xn not written), y = LayerNorm(xn); no statistics kept (timm blocks via src/vision.py:123-134, src/sam.py:231-247). */
+int vrwkv_add_ln_scaled_fwd_bf16(long ntok, int C, float eps, const void* x, const void* delta, const void* dscale, const void* w,
+                                 const void* b, void* xn, void* y, void* stream);
 
 /* Cross-entropy over the vocabulary + L2Wrap gradient (training_step / L2Wrap, VisualRWKV-v7/v7.00/src/model.py:418-434,
  * 257-271), one pass over the (nrows, V) bf16 logits per direction.  labels: int64 per row, the already SHIFTED target

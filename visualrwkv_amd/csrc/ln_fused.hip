@@ -57,7 +57,7 @@ __global__ __launch_bounds__(1024) void add_ln_fwd_kernel(long ntok, int C, floa
                                                           const uint16_t* __restrict__ delta, const uint16_t* __restrict__ w,
                                                           const uint16_t* __restrict__ b, uint16_t* __restrict__ xn,
                                                           uint16_t* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
-                                                          const long* __restrict__ yrow) {
+                                                          const long* __restrict__ yrow, const uint16_t* __restrict__ dscale = nullptr) {
     __shared__ float red[4][MAXW][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int c0 = threadIdx.x * 8;
@@ -66,6 +66,7 @@ __global__ __launch_bounds__(1024) void add_ln_fwd_kernel(long ntok, int C, floa
     if (lo >= hi) return;
     const uint4 z4 = make_uint4(0, 0, 0, 0);
     const V8 wv = unpack8(act ? ldg(w + c0) : z4), bv = unpack8(act ? ldg(b + c0) : z4);
+    const V8 sv = unpack8((act && dscale) ? ldg(dscale + c0) : z4);         // optional per-channel scale of delta (ViT LayerScale)
     const float inv_c = 1.f / (float)C;
     uint4 nx = act ? ldg(x + lo * C + c0) : z4, nd = (act && delta) ? ldg(delta + lo * C + c0) : z4;
     for (long n = lo; n < hi; ++n) {
@@ -77,8 +78,13 @@ __global__ __launch_bounds__(1024) void add_ln_fwd_kernel(long ntok, int C, floa
         V8 v = unpack8(cx);
         if (delta) {
             const V8 d = unpack8(cd);
+            if (dscale) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v.f[e] += d.f[e];
+                for (int e = 0; e < 8; ++e) v.f[e] = fmaf(d.f[e], sv.f[e], v.f[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.f[e] += d.f[e];
+            }
             const uint4 r = pack8(v);
             if (act) *reinterpret_cast<uint4*>(xn + n * C + c0) = r;
             v = unpack8(r);
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(1024) void add_ln_fwd_kernel(long ntok, int C, floa
         for (int e = 0; e < 8; ++e) o.f[e] = fmaf((v.f[e] - mu) * rs, wv.f[e], bv.f[e]);
         const long orow = yrow ? yrow[n] : n;                  // yrow: scatter into a larger tensor; a negative row is dropped
         if (act && orow >= 0) *reinterpret_cast<uint4*>(y + orow * C + c0) = pack8(o);
-        if (threadIdx.x == 0) { mean[n] = mu; rstd[n] = rs; }
+        if (threadIdx.x == 0 && mean) { mean[n] = mu; rstd[n] = rs; }
     }
 }
 
@@ -197,7 +203,20 @@ int vrwkv_add_ln_fwd_bf16(long ntok, int C, float eps, const void* x, const void
     if (!ln_ok(C)) return VRWKV_ESHAPE;
     hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(ln_grid(ntok)), dim3(ln_threads(C)), 0, (hipStream_t)stream, ntok, C, eps,
                        (const uint16_t*)x, (const uint16_t*)delta, (const uint16_t*)w, (const uint16_t*)b, (uint16_t*)xn,
-                       (uint16_t*)y, mean, rstd, (const long*)nullptr);
+                       (uint16_t*)y, mean, rstd, (const long*)nullptr, (const uint16_t*)nullptr);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? VRWKV_OK : (int)e;
+}
+
+// Inference form for the frozen ViT towers (timm pre-LN blocks, src/vision.py:123-134; SAM blocks, src/sam.py:231-247):
+// xn = x + delta * dscale (dscale: LayerScale gamma, may be NULL), y = LayerNorm(xn); no statistics are kept.
+int vrwkv_add_ln_scaled_fwd_bf16(long ntok, int C, float eps, const void* x, const void* delta, const void* dscale, const void* w,
+                                 const void* b, void* xn, void* y, void* stream) {
+    if (ntok <= 0 || !x || !w || !b || !y || (delta && !xn) || (dscale && !delta)) return VRWKV_EINVAL;
+    if (!ln_ok(C)) return VRWKV_ESHAPE;
+    hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(ln_grid(ntok)), dim3(ln_threads(C)), 0, (hipStream_t)stream, ntok, C, eps,
+                       (const uint16_t*)x, (const uint16_t*)delta, (const uint16_t*)w, (const uint16_t*)b, (uint16_t*)xn,
+                       (uint16_t*)y, (float*)nullptr, (float*)nullptr, (const long*)nullptr, (const uint16_t*)dscale);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? VRWKV_OK : (int)e;
 }
@@ -213,7 +232,7 @@ int vrwkv_ln_scatter_fwd_bf16(long ntok, int C, float eps, const void* x, const 
     if (!ln_ok(C)) return VRWKV_ESHAPE;
     hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(ln_grid(ntok)), dim3(ln_threads(C)), 0, (hipStream_t)stream, ntok, C, eps,
                        (const uint16_t*)x, (const uint16_t*)nullptr, (const uint16_t*)w, (const uint16_t*)b, (uint16_t*)nullptr,
-                       (uint16_t*)out, mean, rstd, row_index);
+                       (uint16_t*)out, mean, rstd, row_index, (const uint16_t*)nullptr);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? VRWKV_OK : (int)e;
 }

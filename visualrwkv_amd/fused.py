@@ -401,6 +401,22 @@ def add_ln(x, delta, ln):
     return _AddLN.apply(x, delta, ln.weight, ln.bias, ln.eps)
 
 
+@torch.no_grad()
+def add_ln_infer(x, delta, dscale, ln):
+    """Inference form (frozen ViT towers): returns (x + delta * dscale, LayerNorm(x + delta * dscale)); delta / dscale may be
+    None.  One pass instead of the eager LayerScale multiply, residual add and LayerNorm."""
+    C = x.shape[-1]
+    x = x.contiguous()
+    delta = delta.contiguous() if delta is not None else None
+    _chk(x, delta, ln.weight, ln.bias, dscale)
+    xn = torch.empty_like(x) if delta is not None else x
+    y = torch.empty_like(x)
+    rc = hip_lib.load().vrwkv_add_ln_scaled_fwd_bf16(x.numel() // C, C, float(ln.eps), x.data_ptr(), _p(delta), _p(dscale), ln.weight.data_ptr(),
+                                                     ln.bias.data_ptr(), xn.data_ptr() if delta is not None else 0, y.data_ptr(), _stream(x))
+    hip_lib.check(rc, "vrwkv_add_ln_scaled_fwd_bf16")
+    return xn, y
+
+
 def add_ln_supported(x):
     return x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 64 == 0 and x.shape[-1] <= 8192
 

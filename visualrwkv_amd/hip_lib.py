@@ -26,6 +26,7 @@ PROTOTYPES = {
     "vrwkv_wkv6_backward_bf16": (_c_int, [_c_int] * 4 + [_c_void_p] * 13),
     "vrwkv_add_ln_ws_floats": (_c_long, [_c_long, _c_int]),
     "vrwkv_add_ln_fwd_bf16": (_c_int, [_c_long, _c_int, _c_float] + [_c_void_p] * 9),
+    "vrwkv_add_ln_scaled_fwd_bf16": (_c_int, [_c_long, _c_int, _c_float] + [_c_void_p] * 8),
     "vrwkv_add_ln_bwd_bf16": (_c_int, [_c_long, _c_int] + [_c_void_p] * 10),
     "vrwkv_ce_fwd_bf16": (_c_int, [_c_long, _c_int] + [_c_void_p] * 7),
     "vrwkv_ce_bwd_bf16": (_c_int, [_c_long, _c_int] + [_c_void_p] * 6 + [_c_float] + [_c_void_p] * 2),

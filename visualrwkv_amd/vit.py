@@ -76,6 +76,37 @@ class _Block(nn.Module):
         return x + self.ls2(self.mlp(self.norm2(x)))
 
 
+def _tower_fused(x, dim):
+    """The frozen towers' inference path on the GPU: LayerScale multiply + residual add + LayerNorm in one kernel
+    (csrc/ln_fused.hip, vrwkv_add_ln_scaled_fwd_bf16).  bf16 on the device, no autograd, C a multiple of 64."""
+    return x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled() and dim % 64 == 0 and dim <= 8192
+
+
+def _mlp_infer(mlp, h):
+    """fc2(gelu(fc1(h))); for the tanh-approximated GELU (SigLIP) bias + activation ride in the library GEMM's epilogue."""
+    if mlp.approx == "tanh" and mlp.fc1.bias is not None:
+        shp = h.shape
+        y = torch._addmm_activation(mlp.fc1.bias, h.reshape(-1, shp[-1]), mlp.fc1.weight.t(), use_gelu=True)
+        return mlp.fc2(y).view(*shp[:-1], -1)
+    return mlp(h)
+
+
+def _timm_blocks_infer(blocks, x, last):
+    """blocks 0..last of a timm pre-LN stack on the (x, pending delta * gamma) residual stream (same math as _Block.forward
+    chained: x = x + ls1(attn(norm1(x))); x = x + ls2(mlp(norm2(x))))."""
+    from . import fused
+    delta, scale = None, None
+    for i, blk in enumerate(blocks):
+        g1 = blk.ls1.gamma if isinstance(blk.ls1, _LayerScale) else None
+        g2 = blk.ls2.gamma if isinstance(blk.ls2, _LayerScale) else None
+        x, h = fused.add_ln_infer(x, delta, scale, blk.norm1)
+        x, h = fused.add_ln_infer(x, blk.attn(h), g1, blk.norm2)
+        delta, scale = _mlp_infer(blk.mlp, h), g2
+        if i == last:
+            break
+    return x + (delta * scale if scale is not None else delta)
+
+
 class _PatchEmbed(nn.Module):
     """Non-overlapping patch embedding = one GEMM over unfolded patches (conv with stride = kernel)."""
 
@@ -129,6 +160,8 @@ class TimmViT(nn.Module):
             prefix = [t.expand(x.shape[0], -1, -1) for t in (self.cls_token, self.reg_token) if t is not None]
             if prefix:
                 x = torch.cat(prefix + [x], dim=1)
+        if _tower_fused(x, self.embed_dim) and self.blocks[0].norm1.weight.dtype == torch.bfloat16:
+            return _timm_blocks_infer(self.blocks, x, last)[:, self.num_prefix_tokens:]
         for i, blk in enumerate(self.blocks):
             x = blk(x)
             if i == last:
@@ -202,7 +235,11 @@ class _SamBlock(nn.Module):
 
     def forward(self, x):      # (B, H, W, C)
         short = x
-        x = self.norm1(x)
+        x = self.attn_branch(self.norm1(x))
+        x = short + x
+        return x + self.mlp(self.norm2(x))
+
+    def attn_branch(self, x):  # norm1 output (B, H, W, C) -> attention output, windows partitioned / merged
         ws = self.window_size
         if ws > 0:
             B, H, W, C = x.shape
@@ -215,8 +252,7 @@ class _SamBlock(nn.Module):
             x = x[:, :H, :W].contiguous()
         else:
             x = self.attn(x)
-        x = short + x
-        return x + self.mlp(self.norm2(x))
+        return x
 
 
 class _SamPatchEmbed(nn.Module):
@@ -259,8 +295,17 @@ class SamImageEncoder(nn.Module):
                                   padded_weight=fused.cached_padded_patch_weight(pe, pe.proj.weight)).view(x.shape[0], g, g, -1)
         else:
             x = pe(x) + self.pos_embed
-        for blk in self.blocks:
-            x = blk(x)
+        if _tower_fused(x, x.shape[-1]) and self.blocks[0].norm1.weight.dtype == torch.bfloat16:
+            from . import fused                     # residual adds fused into the LayerNorms (src/sam.py:231-247 chained)
+            delta = None
+            for blk in self.blocks:
+                x, h = fused.add_ln_infer(x, delta, None, blk.norm1)
+                x, h = fused.add_ln_infer(x, blk.attn_branch(h), None, blk.norm2)
+                delta = blk.mlp(h)
+            x = x + delta
+        else:
+            for blk in self.blocks:
+                x = blk(x)
         x = self.neck(x.permute(0, 3, 1, 2))
         B, C, H, W = x.shape                        # space-to-depth: each 2x2 block -> 4C channels
         x = x.view(B, C, H // 2, 2, W // 2, 2).permute(0, 2, 4, 1, 3, 5).reshape(B, H // 2, W // 2, C * 4)
