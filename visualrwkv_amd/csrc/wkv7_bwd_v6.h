@@ -55,7 +55,7 @@ struct LdsV6 {
 static_assert(sizeof(LdsV6) <= 160 * 1024, "LDS budget");
 
 // ------------------------------------------------------------------------------------------ P: operand images + tail
-struct TailRaw { uint2 w, q, k, z, a; };
+struct TailRaw { uint2 q, k, z, a; float x2[4]; };      // inputs kept for the tail: q k z a + log2 c_t (the prep's scan, not recomputed)
 template <bool V> struct BoolTag { static constexpr bool value = V; };
 using RawIn = wkv7v5::RawB;        // w q k z a v dy (uint2) + sa (float4): one lane's 4 channels of one token
 
@@ -85,7 +85,7 @@ DEVFN Decay decay_scan(uint2 wraw) {
     return d;
 }
 
-DEVFN void prep(ChunkImg& B, const RawIn& raw, int c16, int j0, const LaneAddr& la) {
+DEVFN Decay prep(ChunkImg& B, const RawIn& raw, int c16, int j0, const LaneAddr& la) {
     float q[4], k[4], z[4], a[4];
     unpack4(raw.q, q); unpack4(raw.k, k); unpack4(raw.z, z); unpack4(raw.a, a);
     const Decay d = decay_scan(raw.w);
@@ -107,6 +107,7 @@ DEVFN void prep(ChunkImg& B, const RawIn& raw, int c16, int j0, const LaneAddr& 
     const float sav[4] = {raw.sa.x, raw.sa.y, raw.sa.z, raw.sa.w};
     split4(sav, hh, ll); st8(&B.ti[2][la.own], hh); st8(&B.ti[3][la.own], ll);
     if (c16 == 15) *reinterpret_cast<float4*>(&B.cl[j0]) = make_float4(cend[0], cend[1], cend[2], cend[3]);
+    return d;
 }
 
 // element-wise tail of one chunk: lane = token c16, channels 16 pw + 4g + e (the lane's own prep columns)
@@ -121,7 +122,9 @@ DEVFN void tail(const ResImg& R, const TailRaw& tr, const BwdArgs& p, size_t u, 
     const float glv[4] = {gl4.x, gl4.y, gl4.z, gl4.w};
     float q[4], k[4], z[4], a[4];
     unpack4(tr.q, q); unpack4(tr.k, k); unpack4(tr.z, z); unpack4(tr.a, a);
-    const Decay d = decay_scan(tr.w);
+    Decay d;                                              // log2 c_t from the queue; log2 w_t = its difference along t
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { d.x2[e] = tr.x2[e]; d.l2[e] = tr.x2[e] - dpp_shr1_fill(tr.x2[e], 0.f); }
     float dz[4], dq[4], da[4], dk[4], dw[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -298,8 +301,9 @@ __global__ __launch_bounds__(768) void bwd_kernel_v6(BwdArgs p) {
                 WKV_STAMP(0)
                 q2 = q1; q1 = q0;
                 if (FULL || cp >= 0) {
-                    prep(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la);
-                    q0.w = raw.w; q0.q = raw.q; q0.k = raw.k; q0.z = raw.z; q0.a = raw.a;
+                    const Decay dd = prep(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la);
+                    q0.q = raw.q; q0.k = raw.k; q0.z = raw.z; q0.a = raw.a;
+                    q0.x2[0] = dd.x2[0]; q0.x2[1] = dd.x2[1]; q0.x2[2] = dd.x2[2]; q0.x2[3] = dd.x2[3];
                 }
                 WKV_STAMP(1)
                 if (!FULL) vmem_drain();
