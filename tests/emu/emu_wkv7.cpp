@@ -15,7 +15,8 @@ int emu_wkv7_forward(int B, int T, int H, const void* w, const void* q, const vo
     wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                     (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, s, sa};
     dim3 grid((unsigned)(B * H));
-    if (variant == 1) emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1>(p); });                                // round-2 instantiation
+    if (variant == 6) emu::launch(dim3((unsigned)(2 * B * H)), dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1, 1, false, true, true, true>(p); });   // two workgroups per head
+    else if (variant == 1) emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1>(p); });                                // round-2 instantiation
     else if (variant == 2) emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1, 1, false, false, true>(p); });   // no Ab / Kb images
     else emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1, 1, false, true, true>(p); });                      // default: + tr16 reads
     return 0;

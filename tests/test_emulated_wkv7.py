@@ -14,7 +14,7 @@ def P(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-@pytest.mark.parametrize("variant", [-1, 1, 2])   # default (no Ab / Kb images, tr16 reads); 1: round-2 instantiation; 2: no Ab / Kb only
+@pytest.mark.parametrize("variant", [-1, 1, 2, 6])   # default (no Ab / Kb images, tr16 reads); 1: round-2 instantiation; 2: no Ab / Kb only; 6: two workgroups per head
 def test_forward_variants(emu_lib, variant):
     B, T, H, N = 2, 32, 2, 64
     w, q, k, v, z, a, _ = make_inputs(B, T, H, seed=variant + 1)

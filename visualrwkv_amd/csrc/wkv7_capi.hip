@@ -21,6 +21,9 @@ constexpr int BWD_V5_MODE = 2 + 4 + 128;
 // 0.358 -> 0.331 -> 0.324 ms, B=16 0.647 -> 0.637 -> 0.627 ms.  Variant 1 = the round-2 instantiation.
 #define VRWKV_FWD_DEFAULT wkv7c::fwd_kernel_v3<false, false, 1, 1, false, true, true>
 #define VRWKV_FWD_DEFAULT_PROF wkv7c::fwd_kernel_v3<true, false, 1, 1, false, true, true>
+// few heads (B*H <= 128: at most half of the 256 CUs would be busy): two workgroups per head, 32 value rows each
+#define VRWKV_FWD_ISPLIT wkv7c::fwd_kernel_v3<false, false, 1, 1, false, true, true, true>
+constexpr long FWD_ISPLIT_MAX_HEADS = 128;
 // same-box A/B on MI355X, B=16 x 2624 x 32 heads: micro-benchmark (random inputs) 1.042 -> 0.993 ms, inside the training step
 // (bench.py, VRWKV_BWD_VARIANT=5 / 6) 0.981 -> 0.872 ms
 constexpr bool BWD_DEFAULT_V6 = true;
@@ -86,10 +89,12 @@ int vrwkv_wkv7_forward_bf16(int B, int T, int H, const void* w, const void* q, c
         if (g_fwd_variant == 3) kern = &wkv7c::fwd_kernel_v3<false, true, 1, 1, false, false, true>;     // + 16-byte transposed stores
         if (g_fwd_variant == 4) kern = &wkv7c::fwd_kernel_v3<false, false, 1, 1, false, true, true>;     // + natural images read with tr16
         if (g_fwd_variant == 5) kern = &wkv7c::fwd_kernel_v3<false, false, 1, 2, false, false, true>;     // + two chunks of prefetch
+        dim3 g2 = grid;
+        if (g_fwd_variant == -1 && heads <= FWD_ISPLIT_MAX_HEADS) { kern = &VRWKV_FWD_ISPLIT; g2 = dim3((unsigned)(2 * heads)); }
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)sizeof(wkv7c::LdsF));
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kern, grid, dim3(512), sizeof(wkv7c::LdsF), st, p);
+        hipLaunchKernelGGL(kern, g2, dim3(512), sizeof(wkv7c::LdsF), st, p);
     }
     return finish_launch();
 }
@@ -105,11 +110,13 @@ int vrwkv_wkv7_forward_state_bf16(int B, int T, int H, const void* w, const void
         return VRWKV_EALIGN;
     wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                     (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, s_ckpt, sa, nullptr, s0, s_final};
-    auto kern = &VRWKV_FWD_DEFAULT;
+    const long heads = (long)B * H;
+    const bool split = g_fwd_variant == -1 && heads <= FWD_ISPLIT_MAX_HEADS;
+    void (*kern)(wkv7::FwdArgs) = split ? &VRWKV_FWD_ISPLIT : &VRWKV_FWD_DEFAULT;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)sizeof(wkv7c::LdsF));
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((long)B * H)), dim3(512), sizeof(wkv7c::LdsF), (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(split ? 2 * heads : heads)), dim3(512), sizeof(wkv7c::LdsF), (hipStream_t)stream, p);
     return finish_launch();
 }
 

@@ -223,7 +223,10 @@ DEVFN void scores_v3(BufF& B, int pw, int lane) {
 // PF: chunks of input prefetch held in registers by the producers (HBM latency under load exceeds one chunk time);
 // SFX: decay suffix by DPP scan instead of ds_bpermute.
 // NOAB: no Ab / Kb images (the state update multiplies by c_L afterwards) and a T chain that splits every matrix once per level.
-template <bool PROF, bool WIDE = true, int PRIO = 1, int PF = 1, bool SFX = false, bool TRD = false, bool NOAB = false>
+// ISPLIT: two workgroups per (b,h), each owning 32 of the 64 value rows of the state (rows are independent in the forward:
+// sa_i, y_i and S[i][:] only involve row i) -- for few heads (B*H <= 128 leaves half of the 256 CUs idle): every workgroup
+// repeats the producers' work, the consumer chain is halved (consumer waves 2, 3 only keep the barriers company).
+template <bool PROF, bool WIDE = true, int PRIO = 1, int PF = 1, bool SFX = false, bool TRD = false, bool NOAB = false, bool ISPLIT = false>
 __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
     LdsF& lds = *reinterpret_cast<LdsF*>(dyn_lds());
     const int T = p.T, H = p.H;
@@ -232,7 +235,8 @@ __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
     const int c16 = lane & 15, g = lane >> 4;
     const int nchunk = T / L;
     const unsigned ts = (unsigned)(H * N);                              // token stride (elements)
-    const size_t head_base = ((size_t)(blockIdx.x / H) * T * H + (blockIdx.x % H)) * N;
+    const unsigned bh = ISPLIT ? blockIdx.x >> 1 : blockIdx.x;        // (b, h)
+    const size_t head_base = ((size_t)(bh / H) * T * H + (bh % H)) * N;
     WKV_STAMP_DECL
 
     if (wave >= 4) {
@@ -277,11 +281,18 @@ __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
     }
 
     // ---------------------------------------------------------------------- consumers
+    const int wt = ISPLIT ? 2 * (int)(blockIdx.x & 1) + wave : wave;      // which 16 value rows this wave owns
+    const bool idle = ISPLIT && wave >= 2;                                // wave-uniform
+    if (idle) {                                                           // same barrier sequence as the working consumers
+        block_sync_lds(); block_sync_lds();
+        for (int c = 0; c < nchunk; ++c) block_sync_lds();
+        return;
+    }
     f32x4 S[4];
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) S[jb] = zero4();
     if (p.s0) {                                      // S^T[j = 16jb+4g+r][i = 16w+c16] = s0[i][j]: 4 consecutive j per load
-        const float* sp = p.s0 + ((size_t)blockIdx.x * N + 16 * wave + c16) * N + 4 * g;
+        const float* sp = p.s0 + ((size_t)bh * N + 16 * wt + c16) * N + 4 * g;
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) {
             const float4 x = *reinterpret_cast<const float4*>(sp + 16 * jb);
@@ -289,13 +300,13 @@ __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
         }
     }
     // after quad_transpose lane (g, c16) owns row 4g + (c16&3) and the 4 consecutive columns 16w + (c16&~3)..+3
-    const unsigned out_off = WIDE ? (unsigned)(4 * g + (c16 & 3)) * ts + 16u * wave + (c16 & ~3)
-                                  : (unsigned)(4 * g) * ts + 16u * wave + c16;
+    const unsigned out_off = WIDE ? (unsigned)(4 * g + (c16 & 3)) * ts + 16u * wt + (c16 & ~3)
+                                  : (unsigned)(4 * g) * ts + 16u * wt + c16;
     float* psa = p.sa ? p.sa + head_base : nullptr;
     uint16_t* py = p.y + head_base;
-    float* ps = p.s ? p.s + (size_t)blockIdx.x * nchunk * N * N : nullptr;
-    const unsigned s_off = WIDE ? (unsigned)(4 * g + (c16 & 3)) * N + 16u * wave + (c16 & ~3)   // s[j = 16jb+4g+(c16&3)][i..i+3]
-                                : (unsigned)(4 * g) * N + 16u * wave + c16;
+    float* ps = p.s ? p.s + (size_t)bh * nchunk * N * N : nullptr;
+    const unsigned s_off = WIDE ? (unsigned)(4 * g + (c16 & 3)) * N + 16u * wt + (c16 & ~3)   // s[j = 16jb+4g+(c16&3)][i..i+3]
+                                : (unsigned)(4 * g) * N + 16u * wt + c16;
 
     if (tid == 0) lds.prep_done = 0u;
     block_sync_lds();      // prep_done is zeroed
@@ -309,8 +320,8 @@ __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
         const bf16x8 bsh[2] = {mk8(sh[0], sh[1]), mk8(sh[2], sh[3])};
         const bf16x8 bsl[2] = {mk8(sl[0], sl[1]), mk8(sl[2], sl[3])};
         // lane (c16, g) needs v[t = 4g+e][i = 16w + c16]: column c16 of the 4 x 16 block at rows 4g.., columns 16w..
-        const uint2 vv = TRD ? lds_read_tr16(&B.vn[4 * g + (c16 >> 2)][16 * wave + 4 * (c16 & 3)])
-                             : ld8(&B.vt[16 * wave + c16][4 * g]);
+        const uint2 vv = TRD ? lds_read_tr16(&B.vn[4 * g + (c16 >> 2)][16 * wt + 4 * (c16 & 3)])
+                             : ld8(&B.vt[16 * wt + c16][4 * g]);
         const bf16x8 bvv = mk8(vv, vv);
 
         // R = M_zk V + Zt S0^T  (three independent accumulator chains)
@@ -401,7 +412,7 @@ __global__ __launch_bounds__(512) void fwd_kernel_v3(FwdArgs p) {
         WKV_STAMP(5)
     }
     if (p.s_final) {
-        float* sp = p.s_final + ((size_t)blockIdx.x * N + 16 * wave + c16) * N + 4 * g;
+        float* sp = p.s_final + ((size_t)bh * N + 16 * wt + c16) * N + 4 * g;
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) *reinterpret_cast<float4*>(sp + 16 * jb) = make_float4(S[jb][0], S[jb][1], S[jb][2], S[jb][3]);
     }
