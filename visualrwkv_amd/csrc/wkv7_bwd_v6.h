@@ -25,6 +25,9 @@
 #pragma once
 #include <gfx950_prims.h>
 #include <wkv7_chunked.h>
+#ifndef VRWKV_PDELAY
+#define VRWKV_PDELAY 1
+#endif
 #include <wkv7_bwd_v5.h>     // image addressing, dot64, mask_split, regmm_x3, tiles_op, dma_state
 
 namespace wkv7v6 {
@@ -297,6 +300,11 @@ __global__ __launch_bounds__(768) void bwd_kernel_v6(BwdArgs p) {
                 // ran 0.77 -> 0.97 ms: when every CU streams, the loads need most of a step to come back)
                 RawIn nxt;
                 fetch(nxt, cp - 1 > 0 ? cp - 1 : 0);        // unconditional (chunk 0 again past the end): no copies, no early wait
+#if VRWKV_PDELAY
+                // the tail (VALU only) waits until the J waves have split their operands (VALU only as well): it then runs beside
+                // their matrix-core phase instead; J is active in steps 2 .. nchunk + 1 and counts 4 per step
+                if (FULL || (n >= 2 && n <= nchunk + 1)) lds_flag_wait(&lds.flag[3], 4u * (unsigned)(n - 1));
+#endif
                 if (FULL || (ct >= 0 && ct <= nchunk - 1)) tail(lds.res[ct & 1], q2, p, head_base + (size_t)ct * L * ts, lane_boff, c16, w, g, la);
                 WKV_STAMP(0)
                 q2 = q1; q1 = q0;
@@ -471,6 +479,9 @@ __global__ __launch_bounds__(768) void bwd_kernel_v6(BwdArgs p) {
                 bf16x8 s0h[2], s0l[2], duh[2], dul[2];
                 tiles_op(S0, s0h, s0l);
                 tiles_op(dU, duh, dul);
+#if VRWKV_PDELAY
+                lds_flag_add(&lds.flag[3]);
+#endif
                 WKV_STAMP(5)
                 // transposed results: D[m = j][n = t]  (lane = token, registers = 4 consecutive channels of the wave's 16)
                 {

@@ -207,6 +207,26 @@ int vrwkv_wkv7_profile_bf16(int backward, int B, int T, int H, const void* w, co
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7c::LdsF));
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL((VRWKV_FWD_DEFAULT_PROF), grid, dim3(512), sizeof(wkv7c::LdsF), st, p);
+#ifdef VRWKV_V6_EXPERIMENTS
+    } else if (backward >= 20 && backward < 28) {   // the profiling build with roles switched off (20 + SKIP mask: 1 = no P, 2 = no I, 4 = no J)
+        wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
+                        (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
+                        (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da, dbg};
+        void (*kern)(wkv7::BwdArgs) = nullptr;
+        switch (backward - 20) {
+            case 0: kern = &wkv7v6::bwd_kernel_v6<true, 0, 0, 1, false, true, 0>; break;
+            case 1: kern = &wkv7v6::bwd_kernel_v6<true, 0, 0, 1, false, true, 1>; break;
+            case 2: kern = &wkv7v6::bwd_kernel_v6<true, 0, 0, 1, false, true, 2>; break;
+            case 3: kern = &wkv7v6::bwd_kernel_v6<true, 0, 0, 1, false, true, 3>; break;
+            case 4: kern = &wkv7v6::bwd_kernel_v6<true, 0, 0, 1, false, true, 4>; break;
+            case 5: kern = &wkv7v6::bwd_kernel_v6<true, 0, 0, 1, false, true, 5>; break;
+            case 6: kern = &wkv7v6::bwd_kernel_v6<true, 0, 0, 1, false, true, 6>; break;
+            default: kern = &wkv7v6::bwd_kernel_v6<true, 0, 0, 1, false, true, 7>; break;
+        }
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7v6::LdsV6));
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kern, grid, dim3(768), sizeof(wkv7v6::LdsV6), st, p);
+#endif
     } else if (backward == 2) {                     // three-stage pipeline (wkv7_bwd_v6.h): I / J / P wave 0, five stamps each
         wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                         (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
