@@ -47,6 +47,20 @@ def main():
     o1 = fused.mix(xr1, mus[0])
     res["mix1_bwd_ms"] = timeit(lambda: torch.autograd.backward(o1, gouts[:1], retain_graph=True))
     res["mix1_bwd_GBps"] = n * 6 / res["mix1_bwd_ms"] / 1e6
+    # LayerNorm + lerps in one kernel against the two-kernel path (bytes: the two-kernel path's algorithmic bytes)
+    ln = torch.nn.LayerNorm(C).to(dev).bfloat16()
+    delta = torch.randn_like(x)
+    gres = torch.randn_like(x)
+    for M in (6, 1):
+        ms = mus[:M]
+        for name, fwd in (("ln_mix", lambda xx, dd: fused.add_ln_mix(xx, dd, ln, ms, M == 6)),
+                          ("add_ln+mix", lambda xx, dd: (lambda xn, h: (xn, list((fused.mix_dup3 if M == 6 else fused.mix)(h, *ms))))(*fused.add_ln(xx, dd, ln)))):
+            xg, dg = x.clone().requires_grad_(True), delta.clone().requires_grad_(True)
+            with torch.no_grad():
+                res[f"{name}{M}_fwd_ms"] = timeit(lambda: fwd(x, delta))
+            xn, outs = fwd(xg, dg)
+            go = [gouts[i % 6] for i in range(len(outs))]
+            res[f"{name}{M}_bwd_ms"] = timeit(lambda: torch.autograd.backward([xn, *outs], [gres, *go], retain_graph=True))
     print(json.dumps({k: round(v, 3) for k, v in res.items()}))
 
 

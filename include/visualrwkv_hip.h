@@ -97,6 +97,24 @@ int vrwkv_add_ln_fwd_bf16(long ntok, int C, float eps, const void* x, const void
                           void* xn, void* y, float* mean, float* rstd, void* stream);
 int vrwkv_add_ln_bwd_bf16(long ntok, int C, const void* dy, const void* dres, const void* xn, const float* mean,
                           const float* rstd, const void* w, void* dx, float* dwb, float* ws, void* stream);
+
+/* Residual add + LayerNorm + token shift + M lerps in one pass (M = 6: x = x + att(ln1(x)) up to the six inputs of
+ * RWKV_Tmix_x070, VisualRWKV-v7/v7.00/src/model.py:247-254,166-173;  M = 1: ln2 + RWKV_CMix_x070's x_k lerp, :222-223).
+ * xn = bf16(x + delta) (delta NULL: xn is not written), y = bf16(LayerNorm(xn)) is formed in registers only,
+ * out[j][n] = y[n] + (y[n-1] - y[n]) mu[j]  with y[-1] = 0 at the first token of every sample (T tokens per sample);
+ * mean / rstd (ntok) fp32 are kept for the backward.  Bit-identical to vrwkv_add_ln_fwd_bf16 followed by vrwkv_mix_fwd_bf16. */
+long vrwkv_ln_mix_ws_floats(long ntok, int C, int M);
+int vrwkv_ln_mix_fwd_bf16(long ntok, int T, int C, float eps, int M, const void* x, const void* delta, const void* w, const void* b,
+                          const void* const* mu, void* xn, void* const* out, float* mean, float* rstd, void* stream);
+/* backward of the above for M = 1: dx (ntok, C) bf16 = dres + LN'(d y), dwb (2, C) fp32 = (dgamma, dbeta), dmu (M, C) fp32;
+ * dout3_second must be NULL, dres: gradient of xn from the residual path (NULL: none).  M = 6 (VRWKV_ESHAPE here): the six lerps'
+ * backward with y recomputed from xn and the statistics, vrwkv_mix_bwd_ln_bf16, then vrwkv_add_ln_bwd_bf16 on its dx */
+int vrwkv_ln_mix_bwd_bf16(long ntok, int T, int C, int M, const void* xn, const float* mean, const float* rstd, const void* w,
+                          const void* b, const void* const* mu, const void* const* dout, const void* dout3_second, const void* dres,
+                          void* dx, float* dwb, float* dmu, float* ws, void* stream);
+int vrwkv_mix_bwd_ln_bf16(long ntok, int T, int C, int M, const void* xn, const float* mean, const float* rstd, const void* ln_w,
+                          const void* ln_b, const void* const* mu, const void* const* dout, const void* dout3_second, void* dx,
+                          float* dmu, float* ws, void* stream);
 /* Inference form for the frozen ViT towers: xn = x + delta * dscale (dscale = LayerScale gamma (C) bf16 or NULL; delta NULL: no
  * add, xn not written), y = LayerNorm(xn); no statistics kept (timm blocks via src/vision.py:123-134, src/sam.py:231-247). */
 int vrwkv_add_ln_scaled_fwd_bf16(long ntok, int C, float eps, const void* x, const void* delta, const void* dscale, const void* w,

@@ -326,3 +326,50 @@ def test_linear_tn_matches_autograd():
     y2 = lin(x); y2.backward(gy)
     assert torch.equal(y, y2)
     assert rel_rms(gx.float(), x.grad.float()) < 2e-3 and rel_rms(gw.float(), lin.weight.grad.float()) < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,C,M,has_delta,dup3", [(2, 5, 128, 6, True, False), (3, 33, 768, 6, True, True), (1, 40, 2048, 1, True, False),
+                                                    (3, 1, 64, 6, False, False), (7, 592, 256, 6, True, True), (5, 1100, 512, 1, False, False),
+                                                    (8, 2624, 2048, 6, True, True), (8, 2624, 2048, 1, True, False)])
+def test_ln_mix_is_the_two_kernel_path(B, T, C, M, has_delta, dup3):
+    """add + LayerNorm + token shift + lerps in one kernel (fused.add_ln_mix) against add_ln followed by mix: outputs and the
+    input gradients bit-identical (same arithmetic, same roundings), parameter gradients to fp32 summation order.  Shapes with
+    fewer tokens than workgroups, with ranges that straddle sample boundaries, and the benchmark shape."""
+    from visualrwkv_amd import fused
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(B * 1000 + T + C + M)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+    ln = torch.nn.LayerNorm(C).to(dev).bfloat16()
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.2 * rn(C)); ln.bias.copy_(0.1 * rn(C))
+    mus = [torch.rand(1, 1, C, device=dev, generator=g).bfloat16() for _ in range(M)]
+    x0, d0 = rn(B, T, C).bfloat16(), (0.5 * rn(B, T, C)).bfloat16()
+    nout = M + (1 if dup3 else 0)
+    gouts = [rn(B, T, C).bfloat16() for _ in range(nout)]
+    gres = rn(B, T, C).bfloat16()
+
+    def run(fused_path):
+        x, d = x0.clone().requires_grad_(True), (d0.clone().requires_grad_(True) if has_delta else None)
+        ms = [m.clone().requires_grad_(True) for m in mus]
+        for p_ in ln.parameters():
+            p_.grad = None
+        if fused_path:
+            xn, outs = fused.add_ln_mix(x, d, ln, ms, dup3)
+        else:
+            xn, h = fused.add_ln(x, d, ln)
+            outs = list((fused.mix_dup3 if dup3 else fused.mix)(h, *ms))
+        torch.autograd.backward([xn, *outs], [gres, *gouts])
+        return ([xn, *outs], [x.grad] + ([d.grad] if has_delta else []), [m.grad for m in ms] + [ln.weight.grad.clone(), ln.bias.grad.clone()])
+
+    o_f, gx_f, gp_f = run(True)
+    o_r, gx_r, gp_r = run(False)
+    for a, b in zip(o_f, o_r):
+        assert torch.equal(a, b)
+    for a, b in zip(gx_f, gx_r):
+        if has_delta:
+            assert torch.equal(a, b)
+        else:   # without a delta xn is x itself: autograd adds the (rounded) LayerNorm gradient to the residual gradient and rounds again,
+            assert rel_rms(a.float().cpu(), b.float().cpu()) < 3e-3      # the kernel adds in fp32 and rounds once
+    for a, b in zip(gp_f, gp_r):
+        assert rel_rms(a.float().cpu(), b.float().cpu()) < 2e-3       # fp32 partial sums in another order, then one bf16 rounding

@@ -131,12 +131,31 @@ DEVFN void st4f(uint16_t* p, const V4& v) {
 // DUP3: output 3 (x_v of the time-mix) has two consumers (value projection, v-gate LoRA); their gradients arrive as
 // dout.p[3] and dout3b and are summed here instead of by a separate element-wise kernel (3 x 172 MB per layer).
 // DD: per-token lerp weights mu_j + mm_j[n]; additionally writes dmm_j[n] = d_j[n] (x[n-1] - x[n]).
-template <int M, bool DUP3, bool DD = false>
+// LNX: x is not stored -- it is the LayerNorm output of the fused add + LayerNorm + lerps forward (ln_fused.hip: ln_mix_fwd_kernel),
+// recomputed here from xn and the row statistics exactly as that kernel rounded it: bf16(fma((xn - mean) rstd, gamma, beta)).
+struct LnX { const float* mean; const float* rstd; const uint16_t* w; const uint16_t* b; };
+template <int M, bool DUP3, bool DD = false, bool LNX = false>
 __global__ __launch_bounds__(512) void mix_bwd_kernel(long ntok, int T, int C, const uint16_t* __restrict__ x, Ptrs6 mu, Ptrs6 dout,
                                                       const uint16_t* __restrict__ dout3b, uint16_t* __restrict__ dx,
-                                                      float* __restrict__ dmu, Ptrs6 mm = Ptrs6{}, MPtrs6 dmm = MPtrs6{}) {
+                                                      float* __restrict__ dmu, Ptrs6 mm = Ptrs6{}, MPtrs6 dmm = MPtrs6{}, LnX ln = LnX{}) {
     const long lo = ntok * blockIdx.x / gridDim.x, hi = ntok * (blockIdx.x + 1) / gridDim.x;
     for (int c0 = threadIdx.x * 4; c0 < C; c0 += blockDim.x * 4) {
+        uint2 lnw = make_uint2(0u, 0u), lnb = lnw;
+        if (LNX) { lnw = *reinterpret_cast<const uint2*>(ln.w + c0); lnb = *reinterpret_cast<const uint2*>(ln.b + c0); }
+        auto ldx = [&](long row) {                           // row `row` of x, 4 channels
+            V4 t = ld4f(x + row * C + c0);
+            if (LNX) {
+                const float m0 = ln.mean[row], r0 = ln.rstd[row];
+                const float wf[4] = {bf16_lo(lnw.x), bf16_hi(lnw.x), bf16_lo(lnw.y), bf16_hi(lnw.y)};
+                const float bf[4] = {bf16_lo(lnb.x), bf16_hi(lnb.x), bf16_lo(lnb.y), bf16_hi(lnb.y)};
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaf((t.f[e] - m0) * r0, wf[e], bf[e]);
+                const uint32_t p0 = cvt_pk_bf16(o[0], o[1]), p1 = cvt_pk_bf16(o[2], o[3]);
+                t.f[0] = bf16_lo(p0); t.f[1] = bf16_hi(p0); t.f[2] = bf16_lo(p1); t.f[3] = bf16_hi(p1);
+            }
+            return t;
+        };
         V4 m[M], gm[M];
 #pragma unroll
         for (int i = 0; i < M; ++i) {
@@ -146,7 +165,7 @@ __global__ __launch_bounds__(512) void mix_bwd_kernel(long ntok, int T, int C, c
         }
         V4 xprev, aprev;
         {
-            const V4 t = ld4f(x + (lo > 0 ? lo - 1 : 0) * C + c0);
+            const V4 t = ldx(lo > 0 ? lo - 1 : 0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { xprev.f[e] = t.f[e]; aprev.f[e] = 0.f; }
         }
@@ -164,7 +183,7 @@ __global__ __launch_bounds__(512) void mix_bwd_kernel(long ntok, int T, int C, c
 #pragma unroll
                 for (int e = 0; e < 4; ++e) d[M > 3 ? 3 : 0].f[e] += d2.f[e];
             }
-            const V4 xv = ld4f(x + (inside ? n : n - 1) * C + c0);
+            const V4 xv = ldx(inside ? n : n - 1);
             V4 dsum, bv;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { dsum.f[e] = 0.f; bv.f[e] = 0.f; }
@@ -592,6 +611,25 @@ int vrwkv_mix_bwd2_bf16(long ntok, int T, int C, int M, const void* x, const voi
     else if (M == 6) hipLaunchKernelGGL((mix_bwd_kernel<6, false>), dim3(G), dim3(threads), 0, st, ntok, T, C, (const uint16_t*)x, m, d, d2, (uint16_t*)dx, ws, Ptrs6{}, MPtrs6{});
     else if (M == 2) hipLaunchKernelGGL((mix_bwd_kernel<2, false>), dim3(G), dim3(threads), 0, st, ntok, T, C, (const uint16_t*)x, m, d, d2, (uint16_t*)dx, ws, Ptrs6{}, MPtrs6{});
     else hipLaunchKernelGGL((mix_bwd_kernel<1, false>), dim3(G), dim3(threads), 0, st, ntok, T, C, (const uint16_t*)x, m, d, d2, (uint16_t*)dx, ws, Ptrs6{}, MPtrs6{});
+    colsum(G, (long)M * C, ws, dmu, st);
+    return done();
+}
+
+// mix backward when x is the (unstored) LayerNorm output of vrwkv_ln_mix_fwd_bf16: recomputed from xn, mean, rstd, ln_w, ln_b
+int vrwkv_mix_bwd_ln_bf16(long ntok, int T, int C, int M, const void* xn, const float* mean, const float* rstd, const void* ln_w,
+                          const void* ln_b, const void* const* mu, const void* const* dout, const void* dout3_second, void* dx,
+                          float* dmu, float* ws, void* stream) {
+    if (ntok <= 0 || T <= 0 || !xn || !mean || !rstd || !ln_w || !ln_b || !mu || !dout || !dx || !dmu || !ws || M != 6) return VRWKV_EINVAL;
+    if (!ok_c(C) || ntok % T != 0) return VRWKV_ESHAPE;
+    Ptrs6 m{}, d{};
+    for (int i = 0; i < M; ++i) { m.p[i] = (const uint16_t*)mu[i]; d.p[i] = (const uint16_t*)dout[i]; if (!m.p[i] || !d.p[i]) return VRWKV_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    const int G = bwd_grid(ntok);
+    const int threads = C / 4 < 512 ? C / 4 : 512;
+    const uint16_t* d2 = (const uint16_t*)dout3_second;
+    const LnX ln{mean, rstd, (const uint16_t*)ln_w, (const uint16_t*)ln_b};
+    if (d2) hipLaunchKernelGGL((mix_bwd_kernel<6, true, false, true>), dim3(G), dim3(threads), 0, st, ntok, T, C, (const uint16_t*)xn, m, d, d2, (uint16_t*)dx, ws, Ptrs6{}, MPtrs6{}, ln);
+    else hipLaunchKernelGGL((mix_bwd_kernel<6, false, false, true>), dim3(G), dim3(threads), 0, st, ntok, T, C, (const uint16_t*)xn, m, d, d2, (uint16_t*)dx, ws, Ptrs6{}, MPtrs6{}, ln);
     colsum(G, (long)M * C, ws, dmu, st);
     return done();
 }

@@ -417,16 +417,106 @@ def add_ln_infer(x, delta, dscale, ln):
     return xn, y
 
 
+class _AddLnMix(torch.autograd.Function):
+    """(xn, out_0 .. out_{M-1}) = (x + delta, lerps of the token-shifted LayerNorm(x + delta)): `_AddLN` followed by `_Mix` in one
+    kernel each way (csrc/ln_fused.hip: ln_mix_*): the LayerNorm output is never written.  M = 1 (channel-mix) or 6 (time-mix);
+    dup3: a 7th output aliasing output 3 (x_v) for its second consumer, as `_MixDup3`.  delta may be None (first block)."""
+
+    @staticmethod
+    def forward(ctx, x, delta, w, b, eps, dup3, *mus):
+        B, T, C = x.shape
+        M = len(mus)
+        x = x.contiguous()
+        delta = delta.contiguous() if delta is not None else None
+        wc, bc = w.contiguous(), b.contiguous()
+        mus_c = [m.reshape(C).contiguous() for m in mus]
+        _chk(x, delta, wc, bc, *mus_c)
+        ntok = B * T
+        xn = torch.empty_like(x) if delta is not None else x
+        outs = [torch.empty_like(x) for _ in mus]
+        mean = torch.empty(ntok, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(ntok, dtype=torch.float32, device=x.device)
+        rc = hip_lib.load().vrwkv_ln_mix_fwd_bf16(ntok, T, C, float(eps), M, x.data_ptr(), _p(delta), wc.data_ptr(), bc.data_ptr(),
+                                                  _ptr_array(mus_c), xn.data_ptr() if delta is not None else 0, _ptr_array(outs),
+                                                  mean.data_ptr(), rstd.data_ptr(), _stream(x))
+        hip_lib.check(rc, "vrwkv_ln_mix_fwd_bf16")
+        ctx.save_for_backward(xn, mean, rstd, wc, bc, *mus_c)
+        ctx.has_delta = delta is not None
+        ctx.mu_shapes = [m.shape for m in mus]
+        if dup3:
+            outs.append(outs[3].view_as(outs[3]))
+        return (xn, *outs)
+
+    @staticmethod
+    def backward(ctx, d_xn, *douts):
+        xn, mean, rstd, wc, bc, *mus_c = ctx.saved_tensors
+        B, T, C = xn.shape
+        M = len(mus_c)
+        douts = [d.contiguous() for d in douts]
+        d_xn = d_xn.contiguous() if d_xn is not None else None
+        _chk(d_xn, *douts)
+        second = douts[M] if len(douts) > M else None
+        ntok = B * T
+        dx = torch.empty_like(xn)
+        dwb = torch.empty(2, C, dtype=torch.float32, device=xn.device)
+        dmu = torch.empty(M, C, dtype=torch.float32, device=xn.device)
+        lib = hip_lib.load()
+        if M == 1:
+            ws = torch.empty(lib.vrwkv_ln_mix_ws_floats(ntok, C, M), dtype=torch.float32, device=xn.device)
+            rc = lib.vrwkv_ln_mix_bwd_bf16(ntok, T, C, M, xn.data_ptr(), mean.data_ptr(), rstd.data_ptr(), wc.data_ptr(), bc.data_ptr(),
+                                           _ptr_array(mus_c), _ptr_array(douts[:M]), _p(second), _p(d_xn), dx.data_ptr(), dwb.data_ptr(),
+                                           dmu.data_ptr(), ws.data_ptr(), _stream(xn))
+            hip_lib.check(rc, "vrwkv_ln_mix_bwd_bf16")
+        else:       # six lerps: their backward with the LayerNorm output recomputed in place of a stored one, then the LayerNorm's
+            dy = torch.empty_like(xn)
+            ws = _ws(ntok, C, M, xn.device)
+            rc = lib.vrwkv_mix_bwd_ln_bf16(ntok, T, C, M, xn.data_ptr(), mean.data_ptr(), rstd.data_ptr(), wc.data_ptr(), bc.data_ptr(),
+                                           _ptr_array(mus_c), _ptr_array(douts[:M]), _p(second), dy.data_ptr(), dmu.data_ptr(),
+                                           ws.data_ptr(), _stream(xn))
+            hip_lib.check(rc, "vrwkv_mix_bwd_ln_bf16")
+            ws = torch.empty(lib.vrwkv_add_ln_ws_floats(ntok, C), dtype=torch.float32, device=xn.device)
+            rc = lib.vrwkv_add_ln_bwd_bf16(ntok, C, dy.data_ptr(), _p(d_xn), xn.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                           wc.data_ptr(), dx.data_ptr(), dwb.data_ptr(), ws.data_ptr(), _stream(xn))
+            hip_lib.check(rc, "vrwkv_add_ln_bwd_bf16")
+        dwb = dwb.to(wc.dtype)
+        dmu = dmu.to(xn.dtype)
+        return (dx, (dx if ctx.has_delta else None), dwb[0], dwb[1], None, None, *[dmu[i].view(sh) for i, sh in enumerate(ctx.mu_shapes)])
+
+
+def add_ln_mix(x, delta, ln, mus, dup3=False):
+    """Returns (x + delta, [lerp outputs]) -- see `_AddLnMix`."""
+    xn, *outs = _AddLnMix.apply(x, delta, ln.weight, ln.bias, ln.eps, dup3, *mus)
+    return xn, outs
+
+
+LN_MIX = os.environ.get("VRWKV_LN_MIX", "1") != "0"              # A/B switch: 0 = add_ln and mix as two kernels
+LN_MIX_TMIX = os.environ.get("VRWKV_LN_MIX_TMIX", "1") != "0"    # A/B switch: 0 = ln1 and the six time-mix lerps as two kernels
+
+
+def ln_mix_supported(x):
+    return LN_MIX and add_ln_supported(x) and x.dim() == 3 and x.shape[-1] <= 4096
+
+
 def add_ln_supported(x):
     return x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 64 == 0 and x.shape[-1] <= 8192
 
 
 def _block_segment(block, x, delta, v_first):
     """One Block on the (x, pending delta) residual stream: returns (x + delta, ffn output still to be added, v_first)."""
-    x, h = add_ln(x, delta, block.ln1)
-    att_out, v_first = block.att(h, v_first)
+    att, ffn = block.att, block.ffn
+    fuse = ln_mix_supported(x) and getattr(att.args, "fused", False)
+    if fuse and LN_MIX_TMIX:
+        dup3 = torch.is_grad_enabled() and GRAD_ALIAS and att.layer_id > 0
+        x, mixed = add_ln_mix(x, delta, block.ln1, (att.x_r, att.x_w, att.x_k, att.x_v, att.x_a, att.x_g), dup3)
+        att_out, v_first = tmix_from_mixed(att, mixed, v_first)
+    else:
+        x, h = add_ln(x, delta, block.ln1)
+        att_out, v_first = att(h, v_first)
+    if fuse:            # ln2 + the channel-mix lerp in one kernel: the LayerNorm output is never materialised
+        x, (k,) = add_ln_mix(x, att_out, block.ln2, (ffn.x_k,))
+        return x, cmix_from_mixed(ffn, k), v_first
     x, h = add_ln(x, att_out, block.ln2)
-    return x, block.ffn(h), v_first
+    return x, ffn(h), v_first
 
 
 def blocks_forward(rwkv, x, grad_cp=False):
@@ -626,13 +716,18 @@ def blocks6_forward(rwkv, x, wkv=None, grad_cp=False):
 
 def tmix_forward(m, x, v_first):
     """RWKV_Tmix_x070.forward (src/model.py:163-195) with the glue fused; `m` is the module."""
-    B, T, C = x.shape
     train = torch.is_grad_enabled()
     if train and GRAD_ALIAS and m.layer_id > 0:          # x_v, k2, v2 have two consumers each: aliases keep their gradients apart until the
-        xr, xw, xk, xv, xa, xg, xv_b = mix_dup3(x, m.x_r, m.x_w, m.x_k, m.x_v, m.x_a, m.x_g)      # backward kernels sum them
+        mixed = mix_dup3(x, m.x_r, m.x_w, m.x_k, m.x_v, m.x_a, m.x_g)      # backward kernels sum them
     else:
-        xr, xw, xk, xv, xa, xg = mix(x, m.x_r, m.x_w, m.x_k, m.x_v, m.x_a, m.x_g)
-        xv_b = xv
+        mixed = mix(x, m.x_r, m.x_w, m.x_k, m.x_v, m.x_a, m.x_g)
+    return tmix_from_mixed(m, mixed, v_first)
+
+
+def tmix_from_mixed(m, mixed, v_first):
+    """The time-mix after its token shift: `mixed` = (xr, xw, xk, xv, xa, xg[, alias of xv for its second consumer])."""
+    xr, xw, xk, xv, xa, xg = mixed[:6]
+    xv_b = mixed[6] if len(mixed) > 6 else xv
     mm = lora_mm if torch.is_grad_enabled() and LORA_WGRAD else torch.matmul     # training: skinny weight-gradient kernel in the backward
     r = linear(m.receptance, xr)
     w = decay(mm(torch.tanh(mm(xw, m.w1)), m.w2), m.w0)
@@ -704,6 +799,10 @@ def cmix_forward_stateful(m, x, state):
 def cmix_forward(m, x):
     """RWKV_CMix_x070.forward (src/model.py:221-227)."""
     (k,) = mix(x, m.x_k)
+    return cmix_from_mixed(m, k)
+
+
+def cmix_from_mixed(m, k):
     return linear(m.value, relu_sq(linear(m.key, k)))
 
 

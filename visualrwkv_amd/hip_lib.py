@@ -28,6 +28,10 @@ PROTOTYPES = {
     "vrwkv_add_ln_fwd_bf16": (_c_int, [_c_long, _c_int, _c_float] + [_c_void_p] * 9),
     "vrwkv_add_ln_scaled_fwd_bf16": (_c_int, [_c_long, _c_int, _c_float] + [_c_void_p] * 8),
     "vrwkv_add_ln_bwd_bf16": (_c_int, [_c_long, _c_int] + [_c_void_p] * 10),
+    "vrwkv_ln_mix_ws_floats": (_c_long, [_c_long, _c_int, _c_int]),
+    "vrwkv_ln_mix_fwd_bf16": (_c_int, [_c_long, _c_int, _c_int, ctypes.c_float, _c_int] + [_c_void_p] * 10),
+    "vrwkv_ln_mix_bwd_bf16": (_c_int, [_c_long, _c_int, _c_int, _c_int] + [_c_void_p] * 14),
+    "vrwkv_mix_bwd_ln_bf16": (_c_int, [_c_long, _c_int, _c_int, _c_int] + [_c_void_p] * 12),
     "vrwkv_ce_fwd_bf16": (_c_int, [_c_long, _c_int] + [_c_void_p] * 7),
     "vrwkv_ce_bwd_bf16": (_c_int, [_c_long, _c_int] + [_c_void_p] * 6 + [_c_float] + [_c_void_p] * 2),
     "vrwkv_gemv_multi_bf16": (_c_int, [_c_int, _c_int] + [_c_void_p] * 8),
