@@ -445,6 +445,12 @@ __global__ __launch_bounds__(LB, LB <= 256 ? 2 : 1) void ln_mix_bwd_kernel(long 
 
 constexpr int LN_GRID = 2048;
 inline int ln_grid(long ntok) { return (int)(ntok < LN_GRID ? ntok : LN_GRID); }
+// Backward kernels: one workgroup per resident slot (add_ln_bwd: 104 VGPRs, 4 workgroups of 256 threads per CU; ln_mix_bwd<1>: 162, 3 per
+// CU) -- a single round of equal token ranges, and half / a third of the partial rows for ln_colsum_kernel to read (2048 rows cost
+// 46 us per call, 2.3 ms per step)
+constexpr int LN_BWD_GRID = 1024, LN_MIX_BWD_GRID = 768;
+inline int ln_bwd_grid(long ntok) { return (int)(ntok < LN_BWD_GRID ? ntok : LN_BWD_GRID); }
+inline int ln_mix_bwd_grid(long ntok) { return (int)(ntok < LN_MIX_BWD_GRID ? ntok : LN_MIX_BWD_GRID); }
 inline int ln_ok(int C) { return C > 0 && C % 64 == 0 && C <= 8192; }
 inline int ln_threads(int C) { return (C / 8 + 63) / 64 * 64; }
 
@@ -452,7 +458,7 @@ inline int ln_threads(int C) { return (C / 8 + 63) / 64 * 64; }
 
 extern "C" {
 
-long vrwkv_add_ln_ws_floats(long ntok, int C) { return (long)ln_grid(ntok) * 2 * C; }
+long vrwkv_add_ln_ws_floats(long ntok, int C) { return (long)ln_bwd_grid(ntok) * 2 * C; }
 
 int vrwkv_add_ln_fwd_bf16(long ntok, int C, float eps, const void* x, const void* delta, const void* w, const void* b,
                           void* xn, void* y, float* mean, float* rstd, void* stream) {
@@ -499,7 +505,7 @@ int vrwkv_ln_gather_bwd_bf16(long ntok, int C, const void* dout, const long* row
                              const float* rstd, const void* w, void* dx, float* dwb, float* ws, void* stream) {
     if (ntok <= 0 || !dout || !row_index || !x || !mean || !rstd || !w || !dx || !dwb || !ws) return VRWKV_EINVAL;
     if (!ln_ok(C)) return VRWKV_ESHAPE;
-    const int G = ln_grid(ntok);
+    const int G = ln_bwd_grid(ntok);
     hipLaunchKernelGGL(add_ln_bwd_kernel, dim3(G), dim3(ln_threads(C)), 0, (hipStream_t)stream, ntok, C, (const uint16_t*)dout,
                        (const uint16_t*)nullptr, (const uint16_t*)x, mean, rstd, (const uint16_t*)w, (uint16_t*)dx, ws, row_index);
     hipLaunchKernelGGL(ln_colsum_kernel, dim3((unsigned)(2L * C / 64)), dim3(256), 0, (hipStream_t)stream, G, 2L * C, ws, dwb);
@@ -511,7 +517,7 @@ int vrwkv_add_ln_bwd_bf16(long ntok, int C, const void* dy, const void* dres, co
                           const float* rstd, const void* w, void* dx, float* dwb, float* ws, void* stream) {
     if (ntok <= 0 || !dy || !xn || !mean || !rstd || !w || !dx || !dwb || !ws) return VRWKV_EINVAL;
     if (!ln_ok(C)) return VRWKV_ESHAPE;
-    const int G = ln_grid(ntok);
+    const int G = ln_bwd_grid(ntok);
     hipLaunchKernelGGL(add_ln_bwd_kernel, dim3(G), dim3(ln_threads(C)), 0, (hipStream_t)stream, ntok, C, (const uint16_t*)dy,
                        (const uint16_t*)dres, (const uint16_t*)xn, mean, rstd, (const uint16_t*)w, (uint16_t*)dx, ws, (const long*)nullptr);
     hipLaunchKernelGGL(ln_colsum_kernel, dim3((unsigned)(2L * C / 64)), dim3(256), 0, (hipStream_t)stream, G, 2L * C, ws, dwb);
@@ -520,7 +526,7 @@ int vrwkv_add_ln_bwd_bf16(long ntok, int C, const void* dy, const void* dres, co
 }
 
 // Residual add + LayerNorm + token shift + M lerps (M = 1: channel-mix, M = 6: time-mix), see ln_mix_fwd_kernel above.
-long vrwkv_ln_mix_ws_floats(long ntok, int C, int M) { return (long)ln_grid(ntok) * (2 + M) * C; }
+long vrwkv_ln_mix_ws_floats(long ntok, int C, int M) { return (long)ln_mix_bwd_grid(ntok) * (2 + M) * C; }
 
 int vrwkv_ln_mix_fwd_bf16(long ntok, int T, int C, float eps, int M, const void* x, const void* delta, const void* w, const void* b,
                           const void* const* mu, void* xn, void* const* out, float* mean, float* rstd, void* stream) {
@@ -555,7 +561,7 @@ int vrwkv_ln_mix_bwd_bf16(long ntok, int T, int C, int M, const void* xn, const 
         if (!mu[j] || !dout[j]) return VRWKV_EINVAL;
         pm.p[j] = (const uint16_t*)mu[j]; pd.p[j] = (const uint16_t*)dout[j];
     }
-    const int G = ln_grid(ntok);
+    const int G = ln_mix_bwd_grid(ntok);
     const dim3 grid(G), block(ln_threads(C));
     hipStream_t st = (hipStream_t)stream;
     float* part_ln = ws; float* part_mu = ws + (size_t)G * 2 * C;
