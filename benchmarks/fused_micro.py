@@ -47,6 +47,17 @@ def main():
     o1 = fused.mix(xr1, mus[0])
     res["mix1_bwd_ms"] = timeit(lambda: torch.autograd.backward(o1, gouts[:1], retain_graph=True))
     res["mix1_bwd_GBps"] = n * 6 / res["mix1_bwd_ms"] / 1e6
+    # kva (a-gate, value residual, kk normalise, k modulation) and post (GroupNorm + bonus + gate), training form with the aliased outputs
+    kk_, vv_, vf_, vl_, al_ = [torch.randn(B, T, C, device=dev, dtype=torch.bfloat16).requires_grad_(True) for _ in range(5)]
+    kp = [torch.randn(1, 1, C, device=dev, dtype=torch.bfloat16).mul_(0.5).requires_grad_(True) for _ in range(4)]
+    kouts = fused.kva(kk_, vv_, vf_, vl_, al_, *kp, True)
+    kg = [gouts[i % 6] for i in range(len(kouts))]
+    res["kva_fwd_ms"] = timeit(lambda: fused.kva(kk_.detach(), vv_.detach(), vf_.detach(), vl_.detach(), al_.detach(), *[q.detach() for q in kp]))
+    res["kva_bwd_ms"] = timeit(lambda: torch.autograd.backward(kouts, kg, retain_graph=True))
+    yy, rr, gg = [torch.randn(B, T, C, device=dev, dtype=torch.bfloat16).requires_grad_(True) for _ in range(3)]
+    lw, lb_, rk_ = [torch.randn(C, device=dev, dtype=torch.bfloat16).mul_(0.5).requires_grad_(True) for _ in range(3)]
+    pout = fused.post(yy, rr, kk_, vv_, gg, lw, lb_, rk_.view(C // 64, 64), 64e-5)
+    res["post_bwd_ms"] = timeit(lambda: torch.autograd.backward(pout, gouts[0], retain_graph=True))
     # LayerNorm + lerps in one kernel against the two-kernel path (bytes: the two-kernel path's algorithmic bytes)
     ln = torch.nn.LayerNorm(C).to(dev).bfloat16()
     delta = torch.randn_like(x)
