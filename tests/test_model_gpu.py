@@ -183,3 +183,40 @@ def test_full_visual_step_matches_an_independent_fp32_cpu_evaluation(monkeypatch
         loss2 = m.training_step(batch)
     assert float(loss_ref2) < float(loss_ref) and float(loss2) < float(loss)
     assert abs(float(loss2) - float(loss_ref2)) < 1.5e-2 * abs(float(loss_ref2)), (float(loss2), float(loss_ref2))
+
+
+def test_weight_gradients_written_into_the_flat_buffer(monkeypatch):
+    """fused._LinearTN writes a Linear weight's gradient straight into its slot of the ZeRO-1 flat buffer (no bucket copy): the
+    buffer must hold the same bits as with fresh gradient tensors copied in, for one and for two backward passes per step (the
+    second accumulates in place), and `.grad` must be the flat view."""
+    from visualrwkv_amd import fused
+    from visualrwkv_amd.dp import Zero1Engine
+    from visualrwkv_amd.rwkv7 import RWKV
+    args = SimpleNamespace(n_embd=128, n_layer=2, dim_att=128, head_size_a=64, head_size_divisor=8, vocab_size=512, dropout=0,
+                           grad_cp=0, ctx_len=32, fused=True, weight_decay=0.0)
+    torch.manual_seed(0)
+    m = RWKV(args)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() >= 2 and float(p.abs().max()) == 0.0:
+                p.normal_(0, 0.02)
+    m = m.bfloat16().cuda()
+    eng = Zero1Engine(m, lr=1e-3, weight_decay=0.0, grad_clip=1.0, bucket_mb=0.05)
+    ids = torch.randint(0, 512, (2, 32), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+
+    def grads(flat, passes):
+        monkeypatch.setattr(fused, "FLAT_WGRAD", flat)
+        eng.zero_grad()
+        for _ in range(passes):
+            m(m.emb(ids)).float().square().mean().backward()
+        torch.cuda.synchronize()
+        in_place = sum(p.grad is not None and p.grad.data_ptr() == eng._view(k).data_ptr() for k, p in enumerate(eng.params))
+        for b in eng.buckets:           # whatever is still stashed goes into the buffer, as step() would do
+            eng._flush(b)
+        return eng.flat_grad.clone(), in_place
+
+    for passes in (1, 2):
+        g1, n1 = grads(True, passes)
+        g0, n0 = grads(False, passes)
+        assert torch.equal(g1, g0)
+        assert n1 > n0 if passes == 1 else True          # Linear weights sit in the buffer before any copy

@@ -112,6 +112,9 @@ class Zero1Engine:
                 self.flat_param[o:o + p.numel()].copy_(p.data.reshape(-1))
                 p.data = self.flat_param[o:o + p.numel()].view_as(p)
                 p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+                # where this parameter's gradient lives: a backward that owns its weight-gradient GEMM (fused._LinearTN) writes it
+                # there directly and returns that view, which the hook below recognises by its address -- no copy into the bucket
+                p._vrwkv_flat_grad = (self.flat_grad, o)
         # buckets
         self.buckets: List[_Bucket] = []
         s = 0

@@ -94,6 +94,7 @@ lora_mm = _LoraMM.apply
 LORA_WGRAD = os.environ.get("VRWKV_LORA_WGRAD", "1") != "0"      # A/B switch for benchmarks: 0 = autograd's torch.mm
 GRAD_ALIAS = os.environ.get("VRWKV_GRAD_ALIAS", "1") != "0"      # A/B switch: 0 = autograd sums the gradients of x_v, k2, v2
 DGRAD_TN = os.environ.get("VRWKV_DGRAD_TN", "1") != "0"          # A/B switch: 0 = autograd's dy.mm(W) for the input gradient of Linear
+FLAT_WGRAD = os.environ.get("VRWKV_FLAT_WGRAD", "1") != "0"      # A/B switch: 0 = weight gradients as fresh tensors, copied into the ZeRO-1 buffer
 
 
 class _LinearTN(torch.autograd.Function):
@@ -106,6 +107,7 @@ class _LinearTN(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
+        ctx.wparam = w if hasattr(w, "_vrwkv_flat_grad") else None      # the Parameter itself (saved_tensors hands back a plain tensor)
         return F.linear(x, w)
 
     @staticmethod
@@ -115,7 +117,16 @@ class _LinearTN(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = F.linear(dy, transpose2d(w))
         if ctx.needs_input_grad[1]:
-            dw = dy.reshape(-1, dy.shape[-1]).t().mm(x.reshape(-1, x.shape[-1]))
+            dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
+            wp = ctx.wparam
+            if FLAT_WGRAD and wp is not None and wp.grad is None and wp._vrwkv_flat_grad[0].dtype == dy.dtype:
+                # ZeRO-1 engine (dp.Zero1Engine), first gradient of this weight in the step: the GEMM writes into the weight's
+                # slot of the flat gradient buffer; autograd adopts the returned view as `.grad` and the engine finds it in place
+                flat, o = wp._vrwkv_flat_grad
+                dw = flat[o:o + wp.numel()].view(wp.shape)
+                torch.mm(dy2.t(), x2, out=dw)
+            else:
+                dw = dy2.t().mm(x2)
         return dx, dw
 
 
