@@ -207,6 +207,8 @@ def test_weight_gradients_written_into_the_flat_buffer(monkeypatch):
     def grads(flat, passes):
         monkeypatch.setattr(fused, "FLAT_WGRAD", flat)
         eng.zero_grad()
+        if passes == 0:                 # two forward passes under ONE backward: every weight has two gradient producers in the graph
+            (m(m.emb(ids)).float().square().mean() + m(m.emb(ids.flip(1))).float().square().mean()).backward()
         for _ in range(passes):
             m(m.emb(ids)).float().square().mean().backward()
         torch.cuda.synchronize()
@@ -215,8 +217,11 @@ def test_weight_gradients_written_into_the_flat_buffer(monkeypatch):
             eng._flush(b)
         return eng.flat_grad.clone(), in_place
 
-    for passes in (1, 2):
+    for passes in (1, 2, 0):
         g1, n1 = grads(True, passes)
         g0, n0 = grads(False, passes)
-        assert torch.equal(g1, g0)
+        if passes == 0:     # the two gradients of a weight are added by autograd in either order and rounded once more: not bit-equal
+            assert rel_rms(g1.float().cpu(), g0.float().cpu()) < 2e-3
+        else:
+            assert torch.equal(g1, g0)
         assert n1 > n0 if passes == 1 else True          # Linear weights sit in the buffer before any copy

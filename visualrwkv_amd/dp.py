@@ -188,6 +188,7 @@ class Zero1Engine:
         def hook(param):
             g = param.grad
             o = self.offsets[k]
+            param._vrwkv_wgrad_pending = False          # see fused._LinearTN.backward
             if g.data_ptr() != self.flat_grad.data_ptr() + o * self.flat_grad.element_size():
                 self._stash[k] = g                   # autograd handed over a fresh tensor: copied bucket-wise
             self._fired[k] = True
@@ -334,6 +335,7 @@ class Zero1Engine:
         if set_to_none:
             for p in self.params:
                 p.grad = None
+                p._vrwkv_wgrad_pending = False
         else:
             self.flat_grad.zero_()
             for k, p in enumerate(self.params):

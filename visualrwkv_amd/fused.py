@@ -119,12 +119,16 @@ class _LinearTN(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
             wp = ctx.wparam
-            if FLAT_WGRAD and wp is not None and wp.grad is None and wp._vrwkv_flat_grad[0].dtype == dy.dtype:
+            if (FLAT_WGRAD and wp is not None and wp.grad is None and not getattr(wp, "_vrwkv_wgrad_pending", False)
+                    and wp._vrwkv_flat_grad[0].dtype == dy.dtype):
                 # ZeRO-1 engine (dp.Zero1Engine), first gradient of this weight in the step: the GEMM writes into the weight's
-                # slot of the flat gradient buffer; autograd adopts the returned view as `.grad` and the engine finds it in place
+                # slot of the flat gradient buffer; autograd adopts the returned view as `.grad` and the engine finds it in place.
+                # `pending` until the engine's hook has seen it: a second use of the same weight in one graph (two forward passes
+                # under one backward) must not write the slot again while autograd still holds the first gradient there.
                 flat, o = wp._vrwkv_flat_grad
                 dw = flat[o:o + wp.numel()].view(wp.shape)
                 torch.mm(dy2.t(), x2, out=dw)
+                wp._vrwkv_wgrad_pending = True
             else:
                 dw = dy2.t().mm(x2)
         return dx, dw
