@@ -241,6 +241,13 @@ int vrwkv_kva_bwd2_bf16(long ntok, int C, int has_vres, const void* k, const voi
                         const void* dk2, const void* dv2, const void* dz, const void* db, const void* dk2_second,
                         const void* dv2_second, void* dk, void* dv, void* dvfirst, void* dvl, void* dal,
                         float* dparams, float* ws, void* stream);
+/* the same with dvfirst_in (ntok, C) bf16 or NULL added to dvfirst: the layers pass the gradient of v_first down a chain (each layer's
+ * kva returns an alias of v_first for the next layer) instead of autograd summing one term per layer */
+int vrwkv_kva_bwd3_bf16(long ntok, int C, int has_vres, const void* k, const void* v, const void* vfirst, const void* vl, const void* al,
+                        const void* k_k, const void* k_a, const void* a0, const void* v0,
+                        const void* dk2, const void* dv2, const void* dz, const void* db, const void* dk2_second, const void* dv2_second,
+                        const void* dvfirst_in, void* dk, void* dv, void* dvfirst, void* dvl, void* dal,
+                        float* dparams, float* ws, void* stream);
 int vrwkv_post_fwd_bf16(long ntok, int C, float eps, const void* y, const void* r, const void* k, const void* v,
                         const void* g, const void* ln_w, const void* ln_b, const void* r_k, void* out, void* stream);
 int vrwkv_post_bwd_bf16(long ntok, int C, float eps, const void* y, const void* r, const void* k, const void* v,

@@ -327,7 +327,9 @@ struct KvaBwd {
     uint16_t *dk, *dv, *dvfirst, *dvl, *dal;           // outgoing
     float* part;                                       // [grid][4][C] partials of dk_k dk_a da0 dv0
     const uint16_t *dk2b, *dv2b;                       // optional second gradients of k2 / v2 (two consumers: WKV7 and the
-};                                                     // bonus term of `post`), summed here instead of by autograd
+                                                       // bonus term of `post`), summed here instead of by autograd
+    const uint16_t* dvf_in;                            // optional: gradient of v_first collected by the layers after this one
+};
 __global__ void kva_bwd_kernel(KvaBwd p) {
     const int c0 = threadIdx.x * 8, C = p.C;
     const V8 kk_p = ld8f(p.k_k + c0), ka_p = ld8f(p.k_a + c0), a0 = ld8f(p.a0 + c0);
@@ -390,6 +392,11 @@ __global__ void kva_bwd_kernel(KvaBwd p) {
                 dvf.f[e] = dv2.f[e] * sv;
                 dvl.f[e] = dv2.f[e] * (vf.f[e] - v.f[e]) * sv * (1.f - sv);
                 g_v0.f[e] += dvl.f[e];
+            }
+            if (p.dvf_in) {                                      // running sum over the layers (autograd would add 3 x 172 MB per layer)
+                const V8 t = ld8f(p.dvf_in + o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dvf.f[e] += t.f[e];
             }
             st8f(p.dv + o, dv); st8f(p.dvfirst + o, dvf); st8f(p.dvl + o, dvl);
         }
@@ -736,7 +743,17 @@ int vrwkv_kva_bwd2_bf16(long ntok, int C, int has_vres, const void* k, const voi
                         const void* dk2, const void* dv2, const void* dz, const void* db, const void* dk2_second, const void* dv2_second,
                         void* dk, void* dv, void* dvfirst, void* dvl, void* dal,
                         float* dparams, float* ws, void* stream) {
-    if (dv2_second && !has_vres) return VRWKV_EINVAL;
+    return vrwkv_kva_bwd3_bf16(ntok, C, has_vres, k, v, vfirst, vl, al, k_k, k_a, a0, v0, dk2, dv2, dz, db, dk2_second, dv2_second, nullptr,
+                               dk, dv, dvfirst, dvl, dal, dparams, ws, stream);
+}
+// dvfirst_in (optional, has_vres only): added to dvfirst -- the layers hand the gradient of v_first down a chain instead of each
+// returning its own term for autograd to sum
+int vrwkv_kva_bwd3_bf16(long ntok, int C, int has_vres, const void* k, const void* v, const void* vfirst, const void* vl, const void* al,
+                        const void* k_k, const void* k_a, const void* a0, const void* v0,
+                        const void* dk2, const void* dv2, const void* dz, const void* db, const void* dk2_second, const void* dv2_second,
+                        const void* dvfirst_in, void* dk, void* dv, void* dvfirst, void* dvl, void* dal,
+                        float* dparams, float* ws, void* stream) {
+    if ((dv2_second || dvfirst_in) && !has_vres) return VRWKV_EINVAL;
     if (ntok <= 0 || !k || !al || !k_k || !k_a || !a0 || !dk2 || !dz || !db || !dk || !dal || !dparams || !ws) return VRWKV_EINVAL;
     if (has_vres && (!v || !vfirst || !vl || !v0 || !dv2 || !dv || !dvfirst || !dvl)) return VRWKV_EINVAL;
     if (!ok_c(C)) return VRWKV_ESHAPE;
@@ -744,7 +761,7 @@ int vrwkv_kva_bwd2_bf16(long ntok, int C, int has_vres, const void* k, const voi
              (const uint16_t*)k_k, (const uint16_t*)k_a, (const uint16_t*)a0, (const uint16_t*)v0,
              (const uint16_t*)dk2, (const uint16_t*)dv2, (const uint16_t*)dz, (const uint16_t*)db,
              (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dvfirst, (uint16_t*)dvl, (uint16_t*)dal, ws,
-             (const uint16_t*)dk2_second, (const uint16_t*)dv2_second};
+             (const uint16_t*)dk2_second, (const uint16_t*)dv2_second, (const uint16_t*)dvfirst_in};
     const int G = bwd_grid(ntok);
     hipLaunchKernelGGL(kva_bwd_kernel, dim3(G), dim3(C / 8), 0, (hipStream_t)stream, p);
     colsum(G, 4L * C, ws, dparams, (hipStream_t)stream);       // dparams = [dk_k | dk_a | da0 | dv0], C floats each

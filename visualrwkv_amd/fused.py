@@ -94,6 +94,7 @@ lora_mm = _LoraMM.apply
 LORA_WGRAD = os.environ.get("VRWKV_LORA_WGRAD", "1") != "0"      # A/B switch for benchmarks: 0 = autograd's torch.mm
 GRAD_ALIAS = os.environ.get("VRWKV_GRAD_ALIAS", "1") != "0"      # A/B switch: 0 = autograd sums the gradients of x_v, k2, v2
 DGRAD_TN = os.environ.get("VRWKV_DGRAD_TN", "1") != "0"          # A/B switch: 0 = autograd's dy.mm(W) for the input gradient of Linear
+VF_CHAIN = os.environ.get("VRWKV_VF_CHAIN", "1") != "0"          # A/B switch: 0 = every layer returns its own v_first gradient term, autograd adds them
 FLAT_WGRAD = os.environ.get("VRWKV_FLAT_WGRAD", "1") != "0"      # A/B switch: 0 = weight gradients as fresh tensors, copied into the ZeRO-1 buffer
 
 
@@ -234,11 +235,17 @@ class _Decay(torch.autograd.Function):
 class _Kva(torch.autograd.Function):
     """(k, v, v_first, vl, al; k_k, k_a, a0, v0) -> (k2, v2, z, b); v/v_first/vl/v0 are None for layer 0.
     dup=True appends aliases of k2 (and v2) for a second consumer: their gradients reach the backward kernel as
-    separate inputs and are summed there (autograd would run one 3 x 172 MB element-wise add per tensor and layer)."""
+    separate inputs and are summed there (autograd would run one 3 x 172 MB element-wise add per tensor and layer).
+    chain=True (layers > 0) appends an alias of v_first, which the NEXT layer uses as its v_first: the gradient of v_first then
+    travels down the layers as one running sum that each kva backward adds its term to, instead of 23 terms for autograd to add."""
 
     @staticmethod
-    def forward(ctx, k, v, v_first, vl, al, k_k, k_a, a0, v0, dup=False):
+    def forward(ctx, k, v, v_first, vl, al, k_k, k_a, a0, v0, *flags):
+        dup = bool(flags[0]) if len(flags) > 0 else False
         has = v is not None
+        chain = (bool(flags[1]) if len(flags) > 1 else False) and has
+        ctx.nflags = len(flags)
+        ctx.set_materialize_grads(False)         # the last layer's alias of v_first has no consumer: its gradient arrives as None
         k, al = k.contiguous(), al.contiguous()
         C = k.shape[-1]
         ntok = k.numel() // C
@@ -255,11 +262,14 @@ class _Kva(torch.autograd.Function):
         hip_lib.check(rc, "vrwkv_kva_fwd_bf16")
         ctx.has = has
         ctx.dup = bool(dup)
+        ctx.chain = chain
         ctx.shapes = (k_k.shape, k_a.shape, a0.shape, v0.shape if has else None)
         ctx.save_for_backward(k, v, v_first, vl, al, pk, pa, p0, pv)
         outs = (k2, v2, z, b) if has else (k2, z, b)
         if dup:                 # aliases for the second consumer (`post`): autograd then delivers their gradients separately
             outs += (k2.view_as(k2), v2.view_as(v2)) if has else (k2.view_as(k2),)
+        if chain:
+            outs += (v_first.view_as(v_first),)
         return outs
 
     @staticmethod
@@ -267,6 +277,12 @@ class _Kva(torch.autograd.Function):
         k, v, v_first, vl, al, pk, pa, p0, pv = ctx.saved_tensors
         has = ctx.has
         n = 4 if has else 3
+        dvf_in = None
+        if ctx.chain:
+            dvf_in, grads = grads[-1], grads[:-1]
+            dvf_in = dvf_in.contiguous() if dvf_in is not None else None
+        if any(g is None for g in grads):         # set_materialize_grads(False): an output nobody used
+            grads = [g if g is not None else torch.zeros_like(k) for g in grads]
         main, extra = [g.contiguous() for g in grads[:n]], [g.contiguous() for g in grads[n:]]
         if has:
             dk2, dv2, dz, db = main
@@ -275,7 +291,7 @@ class _Kva(torch.autograd.Function):
             dv2 = None
         dk2b = extra[0] if extra else None
         dv2b = extra[1] if len(extra) > 1 else None
-        _chk(dk2, dv2, dz, db, dk2b, dv2b)
+        _chk(dk2, dv2, dz, db, dk2b, dv2b, dvf_in)
         C = k.shape[-1]
         ntok = k.numel() // C
         dk, dal = torch.empty_like(k), torch.empty_like(k)
@@ -284,16 +300,16 @@ class _Kva(torch.autograd.Function):
         dvl = torch.empty_like(k) if has else None
         pg = torch.empty(4, C, dtype=torch.float32, device=k.device)
         ws = _ws(ntok, C, 4, k.device)
-        rc = hip_lib.load().vrwkv_kva_bwd2_bf16(ntok, C, int(has), k.data_ptr(), _p(v), _p(v_first), _p(vl), al.data_ptr(),
+        rc = hip_lib.load().vrwkv_kva_bwd3_bf16(ntok, C, int(has), k.data_ptr(), _p(v), _p(v_first), _p(vl), al.data_ptr(),
                                                 pk.data_ptr(), pa.data_ptr(), p0.data_ptr(), _p(pv),
-                                                dk2.data_ptr(), _p(dv2), dz.data_ptr(), db.data_ptr(), _p(dk2b), _p(dv2b),
+                                                dk2.data_ptr(), _p(dv2), dz.data_ptr(), db.data_ptr(), _p(dk2b), _p(dv2b), _p(dvf_in),
                                                 dk.data_ptr(), _p(dv), _p(dvf), _p(dvl), dal.data_ptr(),
                                                 pg.data_ptr(), ws.data_ptr(), _stream(k))
-        hip_lib.check(rc, "vrwkv_kva_bwd2_bf16")
+        hip_lib.check(rc, "vrwkv_kva_bwd3_bf16")
         pgb = pg.to(k.dtype)
         s = ctx.shapes
         res = (dk, dv, dvf, dvl, dal, pgb[0].view(s[0]), pgb[1].view(s[1]), pgb[2].view(s[2]), pgb[3].view(s[3]) if has else None)
-        return res + (None,) if ctx.dup else res
+        return res + (None,) * ctx.nflags          # dup, chain
 
 
 class _Post(torch.autograd.Function):
@@ -757,7 +773,10 @@ def tmix_from_mixed(m, mixed, v_first):
         v2 = v2_b = v
     else:
         vl = mm(mm(xv_b, m.v1), m.v2)
-        k2, v2, z, b, k2_b, v2_b = kva(k, v, v_first, vl, al, m.k_k, m.k_a, m.a0, m.v0, True)
+        if VF_CHAIN and torch.is_grad_enabled():
+            k2, v2, z, b, k2_b, v2_b, v_first = kva(k, v, v_first, vl, al, m.k_k, m.k_a, m.a0, m.v0, True, True)    # v_first: alias for the next layer
+        else:
+            k2, v2, z, b, k2_b, v2_b = kva(k, v, v_first, vl, al, m.k_k, m.k_a, m.a0, m.v0, True)
         if not GRAD_ALIAS:
             k2_b, v2_b = k2, v2
     y = RUN_CUDA_RWKV7g(r, w, k2, v2, z, b)

@@ -49,6 +49,7 @@ PROTOTYPES = {
     "vrwkv_mix_bwd_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int, _c_int] + [_c_void_p] * 7),
     "vrwkv_mix_bwd2_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int, _c_int] + [_c_void_p] * 8),
     "vrwkv_kva_bwd2_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int] + [_c_void_p] * 23),
+    "vrwkv_kva_bwd3_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int] + [_c_void_p] * 24),
     "vrwkv_ddmix_fwd_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int] + [_c_void_p] * 5),
     "vrwkv_ddmix_bwd_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int] + [_c_void_p] * 9),
     "vrwkv_gn_silu_fwd_bf16": (_c_int, [ctypes.c_long, _c_int, ctypes.c_float] + [_c_void_p] * 6),
