@@ -62,8 +62,8 @@ def _stale() -> bool:
 
 # Per-source extra flags.  attention.hip: no NaN ever enters the softmax (masked logits are -1e30, not -inf), and
 # without -fno-honor-nans every fmaxf of an MFMA result is preceded by a canonicalising v_max x,x,x.
-# wkv7_capi.hip: the SLP vectoriser packs the WKV7 kernels' fp32 element-wise math into v_pk_* instructions, which on gfx950 issue no
-# faster than the two scalar instructions they replace (benchmarks/valu_rate.hip) and need v_mov shuffles to form aligned register
+# wkv7_capi.hip: the SLP vectoriser packs the WKV7 kernels' fp32 element-wise math into v_pk_* instructions, which measured no
+# faster than the two scalar instructions they replace and need v_mov shuffles to form aligned register
 # pairs and cannot take DPP operands (every scan step becomes v_mov_dpp + v_pk_add).  Same-box A/B, alternating processes:
 # forward -1..2 %, backward (v5, v6) -1..2 %.
 EXTRA_FLAGS = {"attention.hip": ["-fno-honor-nans"], "wkv7_capi.hip": ["-fno-slp-vectorize"]}
