@@ -236,6 +236,8 @@ DEVFN uint2 lds_read_tr16(const uint16_t* p) {
     return r;
 }
 DEVFN void lds_dma16(const void* gsrc, void* lds_wave_base) { memcpy((char*)lds_wave_base + 16 * (emu::flat_tid() & 63), gsrc, 16); }
+// empty asm that "redefines" four registers: keeps the compiler from hoisting a derived (e.g. unpacked) form of a loop invariant
+DEVFN void pin_vgpr4(uint32_t&, uint32_t&, uint32_t&, uint32_t&) {}
 DEVFN void vmem_drain() {}
 DEVFN void lds_flag_add(unsigned* cnt) {
     emu::wave_barrier();

@@ -143,6 +143,7 @@ void launch(dim3 grid, dim3 block, F&& body, size_t stack_bytes = 256 * 1024) {
 #define gridDim (emu::gdim())
 
 static inline void __syncthreads() { emu::block_barrier(); }
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }     // device: v_rsq_f32 (1 ulp); parity to the tests' tolerance
 static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }

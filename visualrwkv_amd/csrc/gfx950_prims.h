@@ -196,6 +196,8 @@ DEVFN void lds_dma16(const void* gsrc, void* lds_wave_base) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
+// empty asm that "redefines" four registers: keeps the compiler from hoisting a derived (e.g. unpacked) form of a loop invariant
+DEVFN void pin_vgpr4(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
 DEVFN void vmem_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---------------------------------------------------------------- sync
