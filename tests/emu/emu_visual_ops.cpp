@@ -1,0 +1,4 @@
+// csrc/visual_ops.hip -- kernels and C entry points -- compiled for the host lockstep emulator.  TEST INFRASTRUCTURE ONLY.
+#include <hip/hip_runtime.h>
+#include <gfx950_prims.h>
+#include "../../visualrwkv_amd/csrc/visual_ops.hip"

@@ -34,7 +34,7 @@ def _ln_ref(x, d, w, b, eps):
     var = ((v - mu) ** 2).mean(-1, keepdim=True)
     rs = torch.rsqrt(var + eps)
     y = ((v - mu) * rs * w.float() + b.float()).bfloat16()
-    return xn, y, mu.squeeze(-1), rs.squeeze(-1)
+    return xn, y, mu.squeeze(-1).contiguous(), rs.squeeze(-1).contiguous()
 
 
 def _mix_ref(y, T, mus):
@@ -81,7 +81,7 @@ def test_ln_mix_backward_channel_mix(emu_lib, B, T, C, grid, has_res):
     dwb, dmu = torch.zeros(2 * C), torch.zeros(C)
     f = emu_lib.emu_ln_mix_bwd1
     f.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 11 + [ctypes.c_int]
-    assert f(ntok, T, C, P(xn_r), P(mu_r.contiguous()), P(rs_r.contiguous()), P(w), P(b), P(mus[0]), P(dout), P(dres), P(dx), P(dwb), P(dmu), grid) == 0
+    assert f(ntok, T, C, P(xn_r), P(mu_r), P(rs_r), P(w), P(b), P(mus[0]), P(dout), P(dres), P(dx), P(dwb), P(dmu), grid) == 0
     # reference: autograd in fp64 from the rounded xn
     xv = xn_r.double().requires_grad_(True)
     wv, bv, mv = w.double().requires_grad_(True), b.double().requires_grad_(True), mus[0].double().requires_grad_(True)
