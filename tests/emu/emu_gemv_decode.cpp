@@ -1,0 +1,4 @@
+// csrc/gemv_decode.hip -- kernels and C entry points -- compiled for the host lockstep emulator.  TEST INFRASTRUCTURE ONLY.
+#include <hip/hip_runtime.h>
+#include <gfx950_prims.h>
+#include "../../visualrwkv_amd/csrc/gemv_decode.hip"

@@ -127,3 +127,29 @@ def test_wkv7_single_token_step_against_the_recurrence(emu_lib):
     y_ref, s_ref = wkv7_naive(*[x.double() for x in (w, q, k, v, z, a)])
     assert rel(torch.stack(ys, 1), y_ref) < 3e-3
     assert rel(state, s_ref) < 1e-5
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_decode_gemv_jobs(emu_lib, B):
+    """csrc/gemv_decode.hip: several y = act(x W^T) (+ residual) products of one decode step in one launch (short and long rows, rows
+    split over waves, every activation) on the emulator against fp32 torch -- the CPU twin of tests/test_stateful_gpu.py::
+    test_gemv_multi_matches_torch."""
+    g = torch.Generator().manual_seed(B)
+    rn = lambda *s: (torch.randn(*s, generator=g) * 0.3).bfloat16()
+    jobs = [(rn(256, 512), rn(B, 512), None, 0), (rn(96, 512), rn(B, 512), None, 1), (rn(512, 96), rn(B, 96), rn(B, 512), 0),
+            (rn(70, 64), rn(B, 64), None, 2), (rn(120, 2048), rn(B, 2048), None, 3), (rn(33, 8), rn(B, 8), None, 0),
+            (rn(37, 8192), rn(B, 8192), rn(B, 37), 0)]
+    n = len(jobs)
+    ys = [torch.zeros(B, W.shape[0], dtype=torch.bfloat16) for W, _, _, _ in jobs]
+    arr = lambda ts: (VP * n)(*[t.data_ptr() if t is not None else 0 for t in ts])
+    Ns = (I * n)(*[W.shape[0] for W, _, _, _ in jobs])
+    Ks = (I * n)(*[W.shape[1] for W, _, _, _ in jobs])
+    acts = (I * n)(*[a for _, _, _, a in jobs])
+    call(emu_lib, "vrwkv_gemv_multi_bf16", [I, I] + [VP] * 8, n, B, arr([j[0] for j in jobs]), arr([j[1] for j in jobs]),
+         arr([j[2] for j in jobs]), arr(ys), Ns, Ks, acts, None)
+    for (W, x, res, act), y in zip(jobs, ys):
+        ref = x.float() @ W.float().t()
+        ref = [ref, torch.tanh(ref), torch.sigmoid(ref), torch.relu(ref) ** 2][act]
+        if res is not None:
+            ref = ref + res.float()
+        assert rel(y, ref) < 5e-3, (tuple(W.shape), act)

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(TH_THREADS) void tmix_head_kernel(HeadArgs p) {
     __shared__ float S[64][65];
     __shared__ float part[4][4][64];          // [kind][quarter][channel] partial sums (LoRA, then sa / y of the step)
     __shared__ float vec[6][64];              // decay, q, k, z, a of the step; v2
-    const int tid = threadIdx.x, c = tid & 63, qd = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, c = tid & 63, qd = uniform_i32(tid >> 6);
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const size_t cb = (size_t)b * p.C + h * 64;          // this head's 64 channels of batch row b
     const int hc = h * 64 + c;

@@ -170,7 +170,7 @@ DEVFN int find_job(const GemvArgs& a) {
 }
 
 __global__ __launch_bounds__(GV_THREADS) void gemv_multi_kernel(GemvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];         // [B][K], short-row jobs only
+    float* xs = reinterpret_cast<float*>(dyn_lds());                    // [B][K], short-row jobs only
     const GemvJob job = a.job[find_job(a)];
     const int K = job.K, N = job.N, B = a.B;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_multi_kernel(GemvArgs a) {
 // that E[d^2] - E[d]^2 does not cancel when the row has a large mean.
 template <int CH, int BB>      // chunks per thread (K <= 2048 CH), batch rows compiled in: registers follow the real shape
 __global__ __launch_bounds__(GV_THREADS) void gemv_ln_kernel(GemvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint4 xin[];        // [B][K/8] packed bf16 inputs
+    uint4* xin = reinterpret_cast<uint4*>(dyn_lds());                   // [B][K/8] packed bf16 inputs
     __shared__ float red[4][BB][2];
     const GemvJob job = a.job[find_job(a)];
     const int K = job.K, B = a.B, kchunks = K / 8;
