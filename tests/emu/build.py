@@ -17,7 +17,7 @@ def build_emu(force=False):
     if not force and os.path.exists(SO) and all(os.path.getmtime(d) <= os.path.getmtime(SO) for d in deps):
         return SO
     cxx = CLANG if os.path.exists(CLANG) else "clang++"
-    cmd = [cxx, "-O1", "-std=c++17", "-fPIC", "-shared", "-I", HERE, "-I", CSRC, *srcs, "-o", SO]
+    cmd = [cxx, "-O1", "-std=c++17", "-fPIC", "-shared", "-I", HERE, "-I", CSRC, "-I", os.path.join(ROOT, "include"), *srcs, "-o", SO]
     subprocess.run(cmd, check=True)
     return SO
 
