@@ -112,6 +112,8 @@ int vrwkv_ln_mix_fwd_bf16(long ntok, int T, int C, float eps, int M, const void*
 int vrwkv_ln_mix_bwd_bf16(long ntok, int T, int C, int M, const void* xn, const float* mean, const float* rstd, const void* w,
                           const void* b, const void* const* mu, const void* const* dout, const void* dout3_second, const void* dres,
                           void* dx, float* dwb, float* dmu, float* ws, void* stream);
+/* M = 6: as vrwkv_mix_bwd2_bf16 (dx = gradient of the lerps' input, dmu (M, C) fp32; ws: vrwkv_param_grad_ws_floats(ntok, C, M)) with the
+ * input y = bf16(LayerNorm(xn)) recomputed from xn, mean, rstd, ln_w, ln_b instead of read */
 int vrwkv_mix_bwd_ln_bf16(long ntok, int T, int C, int M, const void* xn, const float* mean, const float* rstd, const void* ln_w,
                           const void* ln_b, const void* const* mu, const void* const* dout, const void* dout3_second, void* dx,
                           float* dmu, float* ws, void* stream);
