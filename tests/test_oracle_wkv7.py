@@ -10,6 +10,7 @@ from oracle.wkv7_oracle import (bf16_round, make_inputs, rel_rms, wkv7_autograd,
                                 wkv7_forward_ref, wkv7_naive)
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "wkv7_simple_ref.pt")
+GOLD64 = os.path.join(os.path.dirname(__file__), "golden", "wkv7_simple_n64_ref.pt")
 
 
 @pytest.fixture(scope="module")
@@ -42,6 +43,45 @@ def test_literal_kernel_restatement_matches_reference_script(gold):
     outs = wkv7_backward_ref(*args, g["dy"].view(B, T, H, N), s, sa, chunk_len=T, dtype=torch.float64, round_out=False)
     for name, o in zip(["dw_raw", "dr", "dk", "dv", "da", "db"], outs):
         assert rel_rms(o, g[name]) < 1e-12, name
+
+
+@pytest.fixture(scope="module")
+def gold64():
+    """The reference's own recurrence loop (RWKV-v7_simple.py:20-32, ast-extracted, fp64) at N = 64 over three 16-token
+    checkpoint chunks -- tests/golden/make_golden_wkv7.py::make_n64."""
+    return torch.load(GOLD64)
+
+
+def test_torch_restatements_match_reference_loop_at_head_size_64(gold64):
+    g = gold64
+    args = [g[n].double() for n in ("w_raw", "q", "k", "v", "z", "a")]
+    y, fin = wkv7_naive(*args)
+    assert rel_rms(y, g["out"]) < 1e-14 and rel_rms(fin, g["final_state"]) < 1e-14
+    _, grads = wkv7_autograd(*[g[n] for n in ("w_raw", "q", "k", "v", "z", "a")], g["dy"])
+    for name, gr in zip(["dw_raw", "dq", "dk", "dv", "dz", "da"], grads):
+        assert rel_rms(gr, g[name]) < 1e-12, name
+    # literal restatement of forward_kernel / backward_kernel in fp64 WITH the 16-token checkpoints and the inverse-decay
+    # un-step across them (wkv7_cuda.cu:44-50, :76-82, :91-95)
+    y2, s, sa = wkv7_forward_ref(*args, dtype=torch.float64, round_y=False)
+    assert rel_rms(y2, g["out"]) < 1e-13
+    assert rel_rms(s[:, :, -1].transpose(-1, -2), g["final_state"]) < 1e-13
+    outs = wkv7_backward_ref(*args, g["dy"].double(), s, sa, dtype=torch.float64, round_out=False)
+    for name, o in zip(["dw_raw", "dq", "dk", "dv", "dz", "da"], outs):
+        assert rel_rms(o, g[name]) < 1e-9, name              # the un-step divides by w: ~1e-11 observed
+
+
+def test_c_oracle_pinned_directly_to_reference_loop_at_head_size_64(gold64):
+    """oracle/wkv7_oracle.c (fp32, N = 64 fixed) against the reference's loop executed in fp64, results rounded ONCE to
+    bf16 as the kernel stores them: forward across two checkpoint boundaries, backward reloading both."""
+    from tests.parity import bf16_close
+    g = gold64
+    args = [g[n] for n in ("w_raw", "q", "k", "v", "z", "a")]
+    y, s, sa = wkv7_c.forward(*args)
+    bf16_close(y, g["out"], "y", tol=1e-3, max_flip=0.01)
+    assert rel_rms(s[:, :, -1].transpose(-1, -2).double(), g["final_state"]) < 2e-6      # fp32 state vs fp64: 3e-7 observed
+    outs = wkv7_c.backward(*args, g["dy"], s, sa)
+    for name, o in zip(["dw_raw", "dq", "dk", "dv", "dz", "da"], outs):
+        bf16_close(o, g[name], name, tol=1e-3, max_flip=0.05 if name in ("dw_raw", "dz") else 0.01)   # dw / dz pass through exp(-exp(w)) and 1/w in fp32: 2.3 % / <1 % flips observed
 
 
 @pytest.mark.parametrize("B,T,H", [(1, 16, 1), (2, 48, 2), (1, 160, 3)])

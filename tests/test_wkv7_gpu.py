@@ -82,6 +82,27 @@ def test_backward_parity(hip_lib, dev, B, T, H, variant):
         assert rel_rms(o.float().cpu(), r.float()) < TOL, n
 
 
+def test_hip_kernels_against_reference_loop_fixture_n64(hip_lib, dev):
+    """The HIP kernels against the reference's own recurrence loop (RWKV-v7_simple.py:20-32 executed in fp64 at
+    (1,48,2,64), tests/golden/wkv7_simple_n64_ref.pt) -- no oracle of this repository in between; both backward kernels."""
+    import os
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "wkv7_simple_n64_ref.pt"))
+    ins = [g[n].to(dev) for n in ("w_raw", "q", "k", "v", "z", "a")]
+    y, s, sa = _capi_forward(hip_lib, *ins)
+    torch.cuda.synchronize()
+    bf16_close(y, g["out"], "y vs reference loop", tol=TOL, max_flip=FLIP_Y)
+    assert rel_rms(s[:, :, -1].transpose(-1, -2).double().cpu(), g["final_state"]) < 2e-5
+    for variant in (5, 6):
+        hip_lib.vrwkv_wkv7_set_backward_variant(variant)
+        try:
+            outs = _capi_backward(hip_lib, *ins, g["dy"].to(dev), s, sa)
+            torch.cuda.synchronize()
+        finally:
+            hip_lib.vrwkv_wkv7_set_backward_variant(-1)
+        for n, o in zip(["dw_raw", "dq", "dk", "dv", "dz", "da"], outs):
+            bf16_close(o, g[n], f"{n} vs reference loop (bwd variant {variant})", tol=TOL, max_flip=FLIP_W if n in ("dw_raw", "dz") else FLIP_G)
+
+
 def test_cfg2_shape_fwd_bwd_parity(hip_lib, dev):
     """BASELINE config 2 shape (0.1B: H=12, T=576+1024=1600), B=1 -- the CPU oracle takes ~1 s."""
     B, T, H = 1, 1600, 12
