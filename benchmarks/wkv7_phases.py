@@ -21,7 +21,7 @@ def run(B=8, T=2624, H=32, bwd_variant=-1, fwd_variant=-1):
     out = {}
     BWD6 = ["I_scores_dM", "I_flagwait", "I_isplit", "I_barrier", "I_top", "J_jsplit", "J_dMwait", "J_products", "J_barrier", "J_top",
             "P_tail", "P_prep", "P_drain", "P_barrier", "P_top", "realtime_100MHz", "J_js_split", "J_js_outputs", "I_is_dSA_dR", "I_is_dV"]
-    for bw, names in ((0, FWD), (1, BWD5), (2, BWD6)):
+    for bw, names in ((0, FWD), (1, BWD5), (2, BWD6), (3, BWD6), (4, BWD6)):
         dbg = torch.zeros(32, dtype=torch.int64, device=dev)
         rc = lib.vrwkv_wkv7_profile_bf16(bw, B, T, H, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), z.data_ptr(), a.data_ptr(),
                                          dy.data_ptr(), y.data_ptr(), s.data_ptr(), sa.data_ptr(), *[x.data_ptr() for x in g], dbg.data_ptr(), st)
@@ -29,13 +29,13 @@ def run(B=8, T=2624, H=32, bwd_variant=-1, fwd_variant=-1):
         torch.cuda.synchronize()
         d = dbg.cpu().tolist()
         nch = T // 16
-        key = ["fwd", "bwd", "bwd_v6"][bw]
+        key = ["fwd", "bwd", "bwd_v6", "bwd_v7", "bwd_v8"][bw]
         out[key] = {n: round(d[i] / nch) for i, n in enumerate(names)}
         out[key + "_total_per_chunk"] = round(sum(d[:15]) / nch)
-        if bw == 2 and d[15] > 0:
+        if bw >= 2 and d[15] > 0:
             cyc = sum(d[0:5]) + d[18] + d[19]            # I wave 0: the five role stamps + the two inner i-split stamps
-            out["bwd_v6_shader_clock_GHz"] = round(cyc / (d[15] * 10.0), 3)
-            out["bwd_v6_cycles_per_step"] = round(cyc / (nch + 3))
+            out[key + "_shader_clock_GHz"] = round(cyc / (d[15] * 10.0), 3)
+            out[key + "_cycles_per_step"] = round(cyc / (nch + 3))
         if bw == 1 and d[7] > 0:      # shader clock while this kernel runs: consumer-wave cycles of workgroup 0 / its life on the 100 MHz counter
             out["bwd_shader_clock_GHz"] = round(sum(d[:7]) / (d[7] * 10.0), 3)
     return out

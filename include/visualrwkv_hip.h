@@ -186,7 +186,10 @@ int vrwkv_wkv7_step_bf16(int B, int H, const void* w, const void* q, const void*
 /* Kernel-generation override for tests and A/B benchmarks; -1 restores the default.
  * forward:  -1 = the default instantiation of csrc/wkv7_fwd_v3.h (chunked MFMA kernel with producer / consumer waves);
  *            1..5 = other instantiations of the same kernel for A/B (csrc/wkv7_capi.hip).
- * backward: -1 = the default (6), 6 = three-stage wave pipeline of 12 waves (csrc/wkv7_bwd_v6.h), 5 = producer / consumer
+ * backward: -1 = the default (8; tensors of 4 GiB and more: 6), 8 = three-role pipeline of 12 waves with ONE copy of dL/dS (handed from
+ *            the i-split to the j-split waves as an operand image), the T chain on a memory-role wave and a memory role that moves
+ *            full 128-byte rows by LDS-DMA (csrc/wkv7_bwd_v8.h), 7 = the v6 schedule with that memory role (csrc/wkv7_bwd_v7.h),
+ *            6 = three-stage wave pipeline with 8-byte-per-lane register loads (csrc/wkv7_bwd_v6.h), 5 = producer / consumer
  *            schedule of 8 waves (csrc/wkv7_bwd_v5.h; also the sequence-parallel kernel).  Anything else: VRWKV_EINVAL. */
 int vrwkv_wkv7_set_forward_variant(int variant);
 int vrwkv_wkv7_set_backward_variant(int variant);

@@ -5,6 +5,8 @@
 #include <wkv7_chunked.h>
 #include <wkv7_fwd_v3.h>
 #include <wkv7_bwd_v6.h>
+#include <wkv7_bwd_v7.h>
+#include <wkv7_bwd_v8.h>
 #include <wkv7_bwd_v5.h>
 #include <wkv6_chunked.h>
 
@@ -41,6 +43,8 @@ int emu_wkv7_backward_chunked(int B, int T, int H, const void* w, const void* q,
     const dim3 grid((unsigned)(B * H));
     if (mode == 6) { emu::launch(grid, dim3(512), [&] { wkv7v5::bwd_kernel_v5<false, 2 + 4 + 128>(p); }); return (int)sizeof(wkv7v5::LdsV5); }
     if (mode == 7) { emu::launch(grid, dim3(768), [&] { wkv7v6::bwd_kernel_v6<false>(p); }); return (int)sizeof(wkv7v6::LdsV6); }   // three-stage wave pipeline
+    if (mode == 8) { emu::launch(grid, dim3(768), [&] { wkv7v7::bwd_kernel_v7<false>(p); }); return (int)sizeof(wkv7v7::LdsV7); }   // + full-row memory role
+    if (mode == 9) { emu::launch(grid, dim3(768), [&] { wkv7v8::bwd_kernel_v8<false>(p); }); return (int)sizeof(wkv7v8::LdsV8); }   // one copy of dS, T on P wave 0
     return -1;
 }
 

@@ -214,6 +214,9 @@ DEVFN f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 }
 
 DEVFN char* dyn_lds() { static __attribute__((aligned(16))) char buf[160 * 1024]; return buf; }
+// LDS "addresses" as 32-bit values: offsets from the start of the (single) dynamic LDS array
+DEVFN unsigned lds_addr_u32(const void* lds_ptr) { return (unsigned)((const char*)lds_ptr - dyn_lds()); }
+DEVFN char* emu_lds_from_u32(unsigned a) { return dyn_lds() + a; }
 
 template <int P> DEVFN void wave_priority() {}
 DEVFN unsigned long long clock64_() { return 0; }
@@ -236,6 +239,14 @@ DEVFN uint2 lds_read_tr16(const uint16_t* p) {
     return r;
 }
 DEVFN void lds_dma16(const void* gsrc, void* lds_wave_base) { memcpy((char*)lds_wave_base + 16 * (emu::flat_tid() & 63), gsrc, 16); }
+DEVFN void lds_dma16_sbase(const void* uniform_base, unsigned lane_byte_off, void* lds_wave_base) {
+    memcpy((char*)lds_wave_base + 16 * (emu::flat_tid() & 63), (const char*)uniform_base + lane_byte_off, 16);
+}
+DEVFN char* emu_lds_from_u32(unsigned a);
+template <int IMM> DEVFN void lds_dma16_lean(const void* uniform_base, unsigned lane_byte_off, unsigned lds_dst_uniform) {
+    memcpy(emu_lds_from_u32(lds_dst_uniform) + IMM + 16 * (emu::flat_tid() & 63), (const char*)uniform_base + lane_byte_off + IMM, 16);   // the immediate moves both ends
+}
+template <int N_> DEVFN void vmem_wait() {}
 // empty asm that "redefines" four registers: keeps the compiler from hoisting a derived (e.g. unpacked) form of a loop invariant
 DEVFN void pin_vgpr4(uint32_t&, uint32_t&, uint32_t&, uint32_t&) {}
 DEVFN void vmem_drain() {}

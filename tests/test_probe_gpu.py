@@ -67,3 +67,13 @@ def test_lds_transpose_read(hip_lib):
         g, i = l >> 4, l & 15
         expect = [float(img[4 * g + e, i]) for e in range(4)]
         assert d[l].tolist() == expect, (l, d[l].tolist(), expect)
+
+
+def test_lds_dma_immediate_offset_moves_both_addresses(hip_lib):
+    """global_load_lds_dwordx4 ... offset:IMM as lds_dma16_lean<IMM> documents (and the emulator models) it: lane l lands at
+    M0 + IMM + 16 l with the bytes of base + lane_offset + IMM -- the immediate is added to the global AND the LDS address."""
+    src = torch.arange(1024, dtype=torch.float32)
+    d = _probe(hip_lib, 8, src.cuda(), None, (1024,)).cpu()
+    expect = torch.full((1024,), -1.0)
+    expect[256:512] = src[256:512]            # IMM = 1024 bytes = 256 floats on both sides, 64 lanes x 4 floats
+    assert torch.equal(d, expect)

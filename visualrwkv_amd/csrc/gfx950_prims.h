@@ -196,6 +196,29 @@ DEVFN void lds_dma16(const void* gsrc, void* lds_wave_base) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
+// the scalar-base form: wave-uniform 64-bit base in SGPRs + one 32-bit byte offset per lane (no 64-bit address arithmetic on
+// the VALU; the offset register can be kept across steps while the base advances on the scalar unit)
+DEVFN void lds_dma16_sbase(const void* uniform_base, unsigned lane_byte_off, void* lds_wave_base) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_wave_base);
+    const unsigned long long ub = (unsigned long long)(uintptr_t)uniform_base;
+    const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)ub), bhi = __builtin_amdgcn_readfirstlane((unsigned)(ub >> 32));
+    const unsigned long long base = ((unsigned long long)bhi << 32) | blo;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_byte_off), "s"(base), "s"(dst) : "memory");
+}
+// the lean form for inner loops: scalar base, 32-bit lane offset, compile-time byte offset (0 .. 4095) that the hardware adds to BOTH
+// the global address and the LDS address (lane l lands at M0 + IMM + 16 l; checked on gfx950: tests/test_probe_gpu.py), and M0
+// is NOT saved / restored -- the kernels that use it never give M0 to the compiler (gfx9 LDS instructions do not read it; the
+// disassembly of csrc/wkv7_capi.hip has no other M0 access), which saves two scalar moves per request: on gfx950 every instruction
+// of any class takes an issue slot of its SIMD (profiles/r4_wkv7_pmc_v6_v8.txt), so they cost what VALU instructions cost
+template <int IMM> DEVFN void lds_dma16_lean(const void* uniform_base, unsigned lane_byte_off, unsigned lds_dst_uniform) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
+                 :: "v"(lane_byte_off), "s"(uniform_base), "s"(lds_dst_uniform), "n"(IMM) : "memory");
+}
+DEVFN unsigned lds_addr_u32(const void* lds_ptr) { return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_ptr); }
+// wait until at most N of this wave's vector-memory operations (loads, LDS-DMA and stores, in issue order) are outstanding
+template <int N_> DEVFN void vmem_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 // empty asm that "redefines" four registers: keeps the compiler from hoisting a derived (e.g. unpacked) form of a loop invariant
 DEVFN void pin_vgpr4(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
 DEVFN void vmem_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

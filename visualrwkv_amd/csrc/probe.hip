@@ -116,6 +116,19 @@ __global__ void probe_tr16(const float* in, float* out) {
     out[l * 4 + 2] = (float)(v.y & 0xffff); out[l * 4 + 3] = (float)(v.y >> 16);
 }
 
+// LDS-DMA with an immediate offset (lds_dma16_lean<1024>): in = 1024 floats; every lane requests in[4 l .. 4 l + 3] (+ the immediate)
+// into an LDS image poisoned with -1; out = the first 1024 floats of the image.  The immediate moves the global AND the LDS address.
+__global__ void probe_dma_imm(const float* in, float* out) {
+    __shared__ __attribute__((aligned(16))) float img[1024];
+    const int l = threadIdx.x;
+    for (int i = l; i < 1024; i += 64) img[i] = -1.f;
+    block_sync();
+    lds_dma16_lean<1024>(in, (unsigned)l * 16u, lds_addr_u32(img));
+    vmem_drain();
+    block_sync();
+    for (int i = l; i < 1024; i += 64) out[i] = img[i];
+}
+
 }  // namespace
 
 // Streaming-copy ceiling of the box (the WKV roofline fraction is reported against the vendor HBM peak and
@@ -203,6 +216,7 @@ extern "C" int vrwkv_debug_probe(int which, const float* a, const float* b, floa
         case 5: hipLaunchKernelGGL(probe_16x16x16_bf16, dim3(1), dim3(64), 0, st, a, b, d); break;
         case 6: hipLaunchKernelGGL(probe_mfma_rate, dim3(1), dim3(64), 0, st, d); break;
         case 7: hipLaunchKernelGGL(probe_tr16, dim3(1), dim3(64), 0, st, a, d); break;
+        case 8: hipLaunchKernelGGL(probe_dma_imm, dim3(1), dim3(64), 0, st, a, d); break;
         default: return VRWKV_EINVAL;
     }
     hipError_t e = hipGetLastError();

@@ -1,94 +1,101 @@
-// WKV7 backward, chunked MFMA form, third-generation schedule: a three-stage wave pipeline -- gfx950.
+// WKV7 backward, chunked MFMA form, fourth-generation schedule: the three-stage wave pipeline of wkv7_bwd_v6.h with a
+// FULL-ROW memory role -- gfx950.
 //
-// Same math and the same operand images as wkv7_bwd_v5.h (closed-form differentiation of a 16-token chunk from S0 = s[c-1]
-// and the saved sa; reference: VisualRWKV-v7/v7.00/cuda/wkv7_cuda.cu:54-130).  What changed is WHO does what and WHEN.
-// The v5 counters (profiles/r2_wkv7_pmc_b16.txt) say the kernel is bound by dependent latency, not by any pipe: per wave
-// and chunk 37 % of the cycles issue an instruction, 27 % stall on issue (MFMA results, LDS queue) and 36 % are parked at
-// s_waitcnt / s_barrier; VALU and matrix pipes are each ~25 % busy.  With 149 KB of LDS only one workgroup fits a CU, so a
-// SIMD holds exactly one consumer and one producer wave, and the consumers walk their three segments (i-split, j-split,
-// score-gradient products + element-wise tail) strictly one after the other.  The only chain that really is sequential
-// from chunk to chunk is dS -> dSA -> dR -> dS (the i-split); everything else hangs off it.
-//
-// Here a workgroup is 12 waves in three roles of four, each SIMD holding one wave of every role, and the roles work on
-// THREE consecutive chunks at the same time (step n, chunks counted down from the end of the sequence):
-//   P  (waves 8-11)  operand images of chunk c-2 (decay scan, scaling, hi/lo split), S0 of chunk c-1 by LDS-DMA, prefetch of
-//                    chunk c-3 -- and the element-wise tail + the five gradient stores of chunk c+1, whose inputs w,q,k,z,a
-//                    it still holds in registers (a four-deep register queue; no `raw` / `dec` images in LDS);
-//   I  (waves 0-3)   scores and T = (I - M_za)^-1 of chunk c-1, then its i-split: dSA, dR, dV, the dS update.  While wave 0
-//                    runs the T chain, waves 1-3 also form the score gradients dM of chunk c for the J waves;
-//   J  (waves 4-7)   j-split of chunk c (products against S0 and dU, second copy of dS) and the dM products; results go to
-//                    LDS as fp32 for the P waves' tail.
-// One workgroup barrier per step; inside a step two LDS counters (scores ready: I -> I, dM ready: I -> J).
-// Per-chunk images live for three steps (three buffers of 24 KB); everything else is single or double buffered by the parity
-// of the chunk that owns it.  The Ab / Kb images of v5 are gone: Ab dS^T = Ah (diag(c_L) dS)^T, and the dS update starts
-// from diag(c_L) dS anyway.  LDS 155 KB.
+// Same math, same roles (P: images + tail, I: scores / T / i-split, J: j-split + score-gradient products) and the same
+// three-chunk pipeline as v6 (reference: VisualRWKV-v7/v7.00/cuda/wkv7_cuda.cu:54-130).  What changed is how the data crosses
+// the chip boundary.  v6's P role loads and stores "one token per lane, four channels = 8 bytes": a wave instruction touches 16
+// token rows x 32 B, every 128-byte line is requested by four different waves.  benchmarks/mem_role_probe.hip (the P role's
+// traffic alone, same occupancy, same step structure; profiles/r4_mem_role_probe.jsonl) prices that shape: 0.94 ms against 0.78 ms
+// for the same bytes moved as full rows at 16 B per lane, reads alone 3.9 -> 5.7 TB/s, writes alone 3.9 -> 5.3 TB/s; the box's
+// plain copy reaches 6.2 TB/s.  Here:
+//   * every input arrives by LDS-DMA as full rows (global_load_lds_dwordx4: 8 lanes = one 128-byte token row of a head, the
+//     XOR swizzle of the operand images applied on the SOURCE address): w q k z a and sa into a staging image the P waves read
+//     their own 8-byte pieces from, v and dy straight into the images the I and J waves read (a ring of four: the slot of chunk
+//     c-3 is free when chunk c+1's rows are requested).  The P role issues no register loads at all: the 36 prefetch registers
+//     of v6 and its pin() bookkeeping are gone, vmcnt only ever counts DMA and the tail's stores.
+//   * staging is single buffered: the P waves lift their pieces into registers at the top of the step, meet on an LDS counter,
+//     and the rows of the next chunk are requested into the same bytes -- nearly a full step before they are needed.
+//   * the J -> P result image is single buffered too (the tail signals when it has read it; the J waves write theirs at the
+//     very end of their step), which pays for the staging image: LDS 157 KB.
 #pragma once
 #include <gfx950_prims.h>
 #include <wkv7_chunked.h>
-#ifndef VRWKV_PDELAY
-#define VRWKV_PDELAY 1
-#endif
-#include <wkv7_bwd_v5.h>     // image addressing, dot64, mask_split, regmm_x3, tiles_op, dma_state
+#include <wkv7_bwd_v6.h>     // Decay, decay_scan, TailRaw, Split16, regmm_pre, BoolTag and (through it) the v5 building blocks
 
-namespace wkv7v6 {
+namespace wkv7v7 {
 
 using wkv7::BwdArgs;
 using namespace wkv7c;
-using namespace wkv7v5;      // IMG, HLI, img_off, f32_off, hl_off, tix, LaneAddr, lane_addr, RawB, ld16, st16, mfma32, ...
+using namespace wkv7v5;      // IMG, HLI, img_off, f32_off, LaneAddr, lane_addr, ld16, st16, mfma32, dot64, mask_split, tiles_op, dma_state
+using wkv7v6::Decay;
+using wkv7v6::decay_scan;
+using wkv7v6::TailRaw;
+using wkv7v6::BoolTag;
 
-struct ChunkImg {                    // per chunk; three alive: P builds c-2, I reads c-1, J reads c
+struct ChunkImg7 {                   // per chunk; three alive: P builds c-2, I reads c-1, J reads c
     uint16_t opnd[8][IMG];           // Zt_h Zt_l Qt_h Qt_l Ah_h Ah_l Kh_h Kh_l      [t][j]
-    uint16_t ti[4][IMG];             // V  dY  SA_h  SA_l                            [t][i]
+    uint16_t sa[2][IMG];             // SA_h  SA_l                                   [t][i]
     float cl[N];                     // c_L[j]
 };
-struct ResImg {                      // J -> P: the four [t][j] results of a chunk before the decay factors, fp32
-    float r[4][IMG];                 // dZt dQt dAh dKh   (f32_off swizzle)
-    float glast[N];                  // sum_i dS_L[i][j] S_L[i][j] at the chunk's last token
-};
-struct LdsV6 {
-    ChunkImg b[3];
+struct LdsV7 {
+    ChunkImg7 b[3];
+    uint16_t vdy[4][2][IMG];         // V, dY [t][i] of chunk c in slot c & 3, written by LDS-DMA (swizzled like every image)
+    uint16_t stg[5][IMG];            // w q k z a of the chunk the P waves prepare next (LDS-DMA; read by the P waves only)
+    float stg_sa[IMG];               // sa of that chunk, fp32, f32_off swizzle
     uint16_t dz[2][IMG];             // "DZ" images of M_zk and T^T (I waves, same step)
     uint16_t sc[2][HLI];             // M_qa, M_qk pair images (I waves, same step)
     uint16_t dsc[4][HLI];            // score gradients of the J waves' chunk (I waves 1-3 -> J waves, same step)
     uint16_t dr[2][2][IMG];          // dR hi, lo [t][i] by chunk parity (I waves -> next step's dM and j-split)
     float s0[2][N * N];              // S0 by chunk parity (P waves' LDS-DMA -> next step's j-split)
-    ResImg res[2];                   // by chunk parity (J waves -> next step's tail)
-    unsigned flag[4];                // 0: M_qa, M_qk, M_zk of this step written (3 per step)   1: dM written (3 per step)   2: T written (1)
+    float res[4][IMG];               // J -> P: dZt dQt dAh dKh before the decay factors, fp32 (single: flag 4 hands it back)
+    float glast[2][N];               // sum_i dS_L[i][j] S_L[i][j] at the chunk's last token, by chunk parity
+    unsigned flag[8];                // 0: M_qa, M_qk, M_zk written (3 per step)  1: dM written (3)  2: T written (1)  3: J operands split (4)
+                                     // 4: tail has read `res` (4)  5: P waves hold their staging pieces (4)
 };
-static_assert(sizeof(LdsV6) <= 160 * 1024, "LDS budget");
+static_assert(sizeof(LdsV7) <= 160 * 1024, "LDS budget");
 
-// ------------------------------------------------------------------------------------------ P: operand images + tail
-struct TailRaw { uint2 q, k, z, a; float x2[4]; };      // inputs kept for the tail: q k z a + log2 c_t (the prep's scan, not recomputed)
-template <bool V> struct BoolTag { static constexpr bool value = V; };
-using RawIn = wkv7v5::RawB;        // w q k z a v dy (uint2) + sa (float4): one lane's 4 channels of one token
+// ------------------------------------------------------------------------------------------ P: rows in, images, tail
+struct RawP { uint2 w, q, k, z, a; float4 sa; };         // one lane's 4 channels of one token, from the staging image
 
-// The compiler waits for a load at the first USE of its destination register and counts vmcnt in issue order; it cannot see
-// the LDS-DMA (inline asm) in between, so a counted wait placed after the DMA also waits for the DMA.  pin() is an empty asm
-// that "uses" the prefetched registers right after the step's own vmem_drain(): the compiler's wait lands there, where
-// everything has retired anyway, and the next step starts with no pending loads in its model.
-DEVFN void pin(RawIn& r) {
-    asm volatile("" : "+v"(r.w.x), "+v"(r.w.y), "+v"(r.q.x), "+v"(r.q.y), "+v"(r.k.x), "+v"(r.k.y), "+v"(r.z.x), "+v"(r.z.y));
-    asm volatile("" : "+v"(r.a.x), "+v"(r.a.y), "+v"(r.v.x), "+v"(r.v.y), "+v"(r.dy.x), "+v"(r.dy.y));
-    asm volatile("" : "+v"(r.sa.x), "+v"(r.sa.y), "+v"(r.sa.z), "+v"(r.sa.w));
-}
-
-// decay scan of one lane's 4 channels over the 16 tokens of the chunk (lane = token c16 inside each 16-lane row)
-struct Decay { float x2[4], l2[4]; };
-DEVFN Decay decay_scan(uint2 wraw) {
-    float wr[4];
-    unpack4(wraw, wr);
-    Decay d;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float lw = -fast_exp2(wr[e] * LOG2E) * LOG2E;          // log2 w_t   (w_t = exp(-exp(w_raw)), wkv7_cuda.cu:21)
-        float x = lw;
-        x += dpp_shr<1>(x); x += dpp_shr<2>(x); x += dpp_shr<4>(x); x += dpp_shr<8>(x);
-        d.x2[e] = x; d.l2[e] = lw;
-    }
+// Full-row requests of one chunk: 18 instructions of 1 KB -- i = 2 arr + half for w q k z a (staging) and v dy (ring slot),
+// then the four quarters of sa -- dealt round-robin to the four P waves (5 5 4 4).  A bf16 row of a head is 128 B = 8 lanes,
+// an fp32 row 256 B = 16 lanes; LDS slot s' of row r receives source slot s' ^ (r & 7) (bf16) / s' ^ (r & 15) (fp32).
+struct DmaLane { unsigned b16, f32; };                   // per-lane byte offsets inside a chunk of a (B,T,H,N) array
+DEVFN DmaLane dma_lane(int lane, unsigned ts) {
+    DmaLane d;
+    const unsigned r8 = (unsigned)lane >> 3, r4 = (unsigned)lane >> 4;
+    d.b16 = r8 * ts * 2u + 16u * (((unsigned)lane & 7u) ^ (r8 & 7u));          // rows 8 half + r8: (row & 7) == r8
+    d.f32 = r4 * ts * 4u + 16u * (((unsigned)lane & 15u) ^ r4);                 // rows 4 qd + r4: (row & 15) == 4 qd + r4 -> ^ 4 qd below
     return d;
 }
+template <class LdsT, int NW = 4>                   // LdsT: .vdy .stg .stg_sa (wkv7_bwd_v8.h reuses these with its own layout); NW issuing waves, this one is w
+DEVFN void dma_chunk(LdsT& lds, const BwdArgs& p, size_t chunk_base /* elements, uniform */, int c, int w, unsigned ts, const DmaLane& dl) {
+    uint16_t* vd = lds.vdy[c & 3][0];
+#pragma unroll
+    for (int k = 0; k < (18 + NW - 1) / NW; ++k) {
+        const int i = w + NW * k;                         // wave-uniform
+        if (i >= 18) break;
+        if (i < 14) {
+            const int arr = i >> 1, half = i & 1;
+            const uint16_t* src = arr == 0 ? p.w : arr == 1 ? p.q : arr == 2 ? p.k : arr == 3 ? p.z : arr == 4 ? p.a : arr == 5 ? p.v : p.dy;
+            uint16_t* dst = (arr < 5 ? lds.stg[arr] : vd + (arr - 5) * IMG) + half * 8 * N;
+            lds_dma16_sbase(src + chunk_base + (size_t)half * 8 * ts, dl.b16, dst);
+        } else {
+            const int qd = i - 14;
+            lds_dma16_sbase(p.sa + chunk_base + (size_t)qd * 4 * ts, dl.f32 ^ (unsigned)(64 * qd), lds.stg_sa + qd * 4 * N);
+        }
+    }
+}
+template <class LdsT>
+DEVFN RawP read_stage(const LdsT& lds, const LaneAddr& la) {
+    RawP r;
+    r.w = ld8(&lds.stg[0][la.own]); r.q = ld8(&lds.stg[1][la.own]); r.k = ld8(&lds.stg[2][la.own]);
+    r.z = ld8(&lds.stg[3][la.own]); r.a = ld8(&lds.stg[4][la.own]);
+    r.sa = *reinterpret_cast<const float4*>(&lds.stg_sa[la.f32]);
+    return r;
+}
 
-DEVFN Decay prep(ChunkImg& B, const RawIn& raw, int c16, int j0, const LaneAddr& la) {
+DEVFN Decay prep7(ChunkImg7& B, const RawP& raw, int c16, int j0, const LaneAddr& la) {
     float q[4], k[4], z[4], a[4];
     unpack4(raw.q, q); unpack4(raw.k, k); unpack4(raw.z, z); unpack4(raw.a, a);
     const Decay d = decay_scan(raw.w);
@@ -105,39 +112,37 @@ DEVFN Decay prep(ChunkImg& B, const RawIn& raw, int c16, int j0, const LaneAddr&
     split4(qt, hh, ll); st8(&B.opnd[2][la.own], hh); st8(&B.opnd[3][la.own], ll);
     split4(ah, hh, ll); st8(&B.opnd[4][la.own], hh); st8(&B.opnd[5][la.own], ll);
     split4(kh, hh, ll); st8(&B.opnd[6][la.own], hh); st8(&B.opnd[7][la.own], ll);
-    st8(&B.ti[0][la.own], raw.v);
-    st8(&B.ti[1][la.own], raw.dy);
     const float sav[4] = {raw.sa.x, raw.sa.y, raw.sa.z, raw.sa.w};
-    split4(sav, hh, ll); st8(&B.ti[2][la.own], hh); st8(&B.ti[3][la.own], ll);
+    split4(sav, hh, ll); st8(&B.sa[0][la.own], hh); st8(&B.sa[1][la.own], ll);
     if (c16 == 15) *reinterpret_cast<float4*>(&B.cl[j0]) = make_float4(cend[0], cend[1], cend[2], cend[3]);
     return d;
 }
 
 // element-wise tail of one chunk: lane = token c16, channels 16 pw + 4g + e (the lane's own prep columns)
-DEVFN void tail(const ResImg& R, const TailRaw& tr, const BwdArgs& p, size_t u, unsigned lane_boff, int c16, int pw, int g, const LaneAddr& la) {
-    const float4 zt4 = *reinterpret_cast<const float4*>(&R.r[0][la.f32]);
-    const float4 qt4 = *reinterpret_cast<const float4*>(&R.r[1][la.f32]);
-    const float4 ah4 = *reinterpret_cast<const float4*>(&R.r[2][la.f32]);
-    const float4 kh4 = *reinterpret_cast<const float4*>(&R.r[3][la.f32]);
-    const float4 gl4 = *reinterpret_cast<const float4*>(&R.glast[16 * pw + 4 * g]);
+template <class LdsT>                               // LdsT: .res .glast .flag
+DEVFN void tail7(LdsT& lds, int par, const TailRaw& tr, const BwdArgs& p, size_t u, unsigned lane_boff, int c16, int pw, int g, const LaneAddr& la) {
+    const float4 zt4 = *reinterpret_cast<const float4*>(&lds.res[0][la.f32]);
+    const float4 qt4 = *reinterpret_cast<const float4*>(&lds.res[1][la.f32]);
+    const float4 ah4 = *reinterpret_cast<const float4*>(&lds.res[2][la.f32]);
+    const float4 kh4 = *reinterpret_cast<const float4*>(&lds.res[3][la.f32]);
+    const float4 gl4 = *reinterpret_cast<const float4*>(&lds.glast[par][16 * pw + 4 * g]);
+    lds_flag_add(&lds.flag[4]);                           // (waits for the reads above) the J waves may overwrite `res`
     const float dZt[4] = {zt4.x, zt4.y, zt4.z, zt4.w}, dQt[4] = {qt4.x, qt4.y, qt4.z, qt4.w};
     const float dAh[4] = {ah4.x, ah4.y, ah4.z, ah4.w}, dKh[4] = {kh4.x, kh4.y, kh4.z, kh4.w};
     const float glv[4] = {gl4.x, gl4.y, gl4.z, gl4.w};
     float q[4], k[4], z[4], a[4];
     unpack4(tr.q, q); unpack4(tr.k, k); unpack4(tr.z, z); unpack4(tr.a, a);
-    Decay d;                                              // log2 c_t from the queue; log2 w_t = its difference along t
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { d.x2[e] = tr.x2[e]; d.l2[e] = tr.x2[e] - dpp_shr1_fill(tr.x2[e], 0.f); }
     float dz[4], dq[4], da[4], dk[4], dw[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float cc = fast_exp2(d.x2[e]), ic = fast_exp2(-d.x2[e]), cp = dpp_shr1_fill(cc, 1.f);
+        const float x2 = tr.x2[e], l2 = x2 - dpp_shr1_fill(x2, 0.f);      // log2 c_t from the queue; log2 w_t = its difference along t
+        const float cc = fast_exp2(x2), ic = fast_exp2(-x2), cp = dpp_shr1_fill(cc, 1.f);
         dz[e] = dZt[e] * cp; dq[e] = dQt[e] * cc; da[e] = dAh[e] * ic; dk[e] = dKh[e] * ic;
         // decay-gradient integrand g_t = dq q - da a - dk k + (dz z)[t+1]  (+ sum_i dS.S_L at the last token)
         float gt = dq[e] * q[e] - da[e] * a[e] - dk[e] * k[e] + dpp_shl<1>(dz[e] * z[e]);
         if (c16 == 15) gt += glv[e];
         gt += dpp_shl<1>(gt); gt += dpp_shl<2>(gt); gt += dpp_shl<4>(gt); gt += dpp_shl<8>(gt);   // suffix sum over t
-        dw[e] = gt * (d.l2[e] * LN2);
+        dw[e] = gt * (l2 * LN2);
     }
     auto out = [&](uint16_t* base) { return reinterpret_cast<uint2*>(reinterpret_cast<char*>(base + u) + lane_boff); };   // uniform base + lane offset
     *out(p.dw) = make_uint2(cvt_pk_bf16(dw[0], dw[1]), cvt_pk_bf16(dw[2], dw[3]));
@@ -147,114 +152,31 @@ DEVFN void tail(const ResImg& R, const TailRaw& tr, const BwdArgs& p, size_t u, 
     *out(p.da) = make_uint2(cvt_pk_bf16(da[0], da[1]), cvt_pk_bf16(da[2], da[3]));
 }
 
-// U^T V for 16x16 register matrices in C layout with the operands already split (see wkv7v5::regmm_x3): a level of the
-// doubling uses every matrix twice, so each is split once (4 splits per level instead of 6: -72 VALU on the T chain's wave)
-struct Split16 { uint2 h, l; };
-DEVFN Split16 split16(f32x4 x) { Split16 s; split4(x, s.h, s.l); return s; }
-// FULLX: the second MFMA re-uses the first one's X operand [u_h | u_l] against [v_l ; v_l] (the full product, u_l v_l included)
-// instead of [u_h | 0] x [v_l ; 0]: one 4-register operand less to assemble per product (the T chain is ~30 % register moves)
-template <bool FULLX = false>
-DEVFN f32x4 regmm_pre(const Split16& u, const Split16& v) {
-    const bf16x8 x = mk8(u.h, u.l);
-    const f32x4 acc = mfma32(x, mk8(v.h, v.h), zero4());
-    if (FULLX) return mfma32(x, mk8(v.l, v.l), acc);
-    return mfma32(mk8(u.h.x, u.h.y, 0u, 0u), mk8(v.l.x, v.l.y, 0u, 0u), acc);
-}
-
-// ------------------------------------------------------------------------------------------ I: scores, T, score gradients
-// piece 0: T (DZ image of T^T)   1: M_qa   2: M_qk   3: M_zk (DZ image)
-template <bool DBL_BF16, class LdsT, class ImgT, bool FULLX = false>       // LdsT: .sc, .dz   ImgT: .opnd   (wkv7_bwd_v7.h / v8.h reuse this with their own layouts)
-DEVFN void scores6(LdsT& lds, const ImgT& B, int piece, int c16, int g, const LaneAddr& la) {
-    uint2 hh, ll;
-    if (piece == 1) {            // image[t][s] = M_qa[s][t] = Qt_s . Ah_t , s >= t
-        mask_split<true, true>(dot64<true, true>(B.opnd[2], B.opnd[3], B.opnd[4], B.opnd[5], la), c16, g, hh, ll);
-        st16(lds.sc[0] + la.hl, hh, ll);
-    } else if (piece == 2) {     // M_qk[s][t] = Qt_s . Kh_t , s >= t
-        mask_split<true, true>(dot64<true, true>(B.opnd[2], B.opnd[3], B.opnd[6], B.opnd[7], la), c16, g, hh, ll);
-        st16(lds.sc[1] + la.hl, hh, ll);
-    } else if (piece == 3) {     // M_zk[s][t] = Zt_s . Kh_t , s > t      (DZ image)
-        mask_split<false, true>(dot64<true, true>(B.opnd[0], B.opnd[1], B.opnd[6], B.opnd[7], la), c16, g, hh, ll);
-        st16(lds.dz[0] + la.row[0], hh, hh);
-        st16(lds.dz[0] + la.row[1], ll, make_uint2(0u, 0u));
-    } else {                     // T = (I - M_za)^-1 by nilpotent doubling, register resident     (DZ image of T^T)
-        f32x4 X, XT, Tc;
-        {
-            const bf16x8 zh0 = ld16(B.opnd[0] + la.row[0]), zl0 = ld16(B.opnd[1] + la.row[0]);
-            const bf16x8 ah0 = ld16(B.opnd[4] + la.row[0]), al0 = ld16(B.opnd[5] + la.row[0]);
-            const bf16x8 zh1 = ld16(B.opnd[0] + la.row[1]), zl1 = ld16(B.opnd[1] + la.row[1]);
-            const bf16x8 ah1 = ld16(B.opnd[4] + la.row[1]), al1 = ld16(B.opnd[5] + la.row[1]);
-            X = mfma32(zh0, ah0, zero4()); XT = mfma32(ah0, zh0, zero4());
-            X = mfma32(zh0, al0, X);       XT = mfma32(al0, zh0, XT);
-            X = mfma32(zl0, ah0, X);       XT = mfma32(ah0, zl0, XT);
-            X = mfma32(zh1, ah1, X);       XT = mfma32(ah1, zh1, XT);
-            X = mfma32(zh1, al1, X);       XT = mfma32(al1, zh1, XT);
-            X = mfma32(zl1, ah1, X);       XT = mfma32(ah1, zl1, XT);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            X[r] = (c16 < 4 * g + r) ? X[r] : 0.f;
-            XT[r] = (4 * g + r < c16) ? XT[r] : 0.f;
-            Tc[r] = X[r] + ((4 * g + r == c16) ? 1.f : 0.f);
-        }
-        if (DBL_BF16) {
-            Split16 sx = split16(X), sxt = split16(XT);
-#pragma unroll
-            for (int level = 0; level < 3; ++level) {
-                const f32x4 XTn = regmm_pre<FULLX>(sx, sxt);         // (X^T)^2
-                f32x4 Xn = X;
-                if (level < 2) Xn = regmm_pre<FULLX>(sxt, sx);       // X^2
-                const Split16 sxtn = split16(XTn);
-                const f32x4 D = regmm_pre<FULLX>(sxtn, split16(Tc)); // X_k T
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Tc[r] += D[r];
-                X = Xn; XT = XTn;
-                sxt = sxtn;
-                if (level < 2) sx = split16(Xn);
-            }
-        } else {
-#pragma unroll
-            for (int level = 0; level < 3; ++level) {
-                const f32x4 XTn = regmm_f32x2(X, XT);                // exact f32 matrix core: 4 MFMAs of 32 cycles, no VALU
-                f32x4 Xn = X;
-                if (level < 2) Xn = regmm_f32x2(XT, X);
-                const f32x4 D = regmm_f32x2(XTn, Tc);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Tc[r] += D[r];
-                X = Xn; XT = XTn;
-            }
-        }
-        split4(Tc, hh, ll);                                      // Tc[r] = T[4g+r][c16] -> image[c16][4g+r]
-        st16(lds.dz[1] + la.row[0], hh, hh);
-        st16(lds.dz[1] + la.row[1], ll, make_uint2(0u, 0u));
-    }
-}
 // score gradients image[t][s] = dM[t][s]: D[m = s][n = t] = X_s . Y_t with X in {SA, V}, Y in {dR, dY}; pair images
 // piece 0 dM_za  1 dM_zk  2 dM_qa  3 dM_qk
-DEVFN void dscores6(LdsV6& lds, const ChunkImg& B, const uint16_t* drh, const uint16_t* drl, int piece, int c16, int g, const LaneAddr& la) {
+template <class LdsT>                               // LdsT: .dsc
+DEVFN void dscores7(LdsT& lds, const uint16_t* sah, const uint16_t* sal, const uint16_t* vi, const uint16_t* dyi,
+                    const uint16_t* drh, const uint16_t* drl, int piece, int c16, int g, const LaneAddr& la) {
     uint2 hh, ll;
-    if (piece == 0) mask_split<false, false>(dot64<true, true>(B.ti[2], B.ti[3], drh, drl, la), c16, g, hh, ll);              // tril_(dR SA^T)
-    else if (piece == 1) mask_split<false, false>(dot64<false, true>(B.ti[0], B.ti[0], drh, drl, la), c16, g, hh, ll);       // tril_(dR V^T)
-    else if (piece == 2) mask_split<true, false>(dot64<true, false>(B.ti[2], B.ti[3], B.ti[1], B.ti[1], la), c16, g, hh, ll);  // tril(dY SA^T)
-    else mask_split<true, false>(dot64<false, false>(B.ti[0], B.ti[0], B.ti[1], B.ti[1], la), c16, g, hh, ll);                // tril(dY V^T)
+    if (piece == 0) mask_split<false, false>(dot64<true, true>(sah, sal, drh, drl, la), c16, g, hh, ll);              // tril_(dR SA^T)
+    else if (piece == 1) mask_split<false, false>(dot64<false, true>(vi, vi, drh, drl, la), c16, g, hh, ll);         // tril_(dR V^T)
+    else if (piece == 2) mask_split<true, false>(dot64<true, false>(sah, sal, dyi, dyi, la), c16, g, hh, ll);        // tril(dY SA^T)
+    else mask_split<true, false>(dot64<false, false>(vi, vi, dyi, dyi, la), c16, g, hh, ll);                         // tril(dY V^T)
     const int o = la.hl + 4 * (piece & 1);                   // za / qa first, zk / qk second of the pair
     st8(&lds.dsc[piece & 2][o], hh);
     st8(&lds.dsc[(piece & 2) + 1][o], ll);
 }
 
 // ------------------------------------------------------------------------------------------ kernel
-// dbg (PROF): [0..4] I wave 0: scores | flag wait | i-split | barrier | -   [5..9] J wave 0: j-split | dM wait | products |
-// barrier | -   [10..14] P wave 0: tail | prep | drain | barrier | -   [15] life of workgroup 0 on the 100 MHz counter
-// PI / PJ / PP: static wave priority of the three roles; SWAP: the J role on the oldest waves (0-3), I on 4-7 (VALU issue is
-// arbitrated by priority, then age: MI355X_MICROARCH.md "Two waves per SIMD").
-// SKIP (timing experiments only, results are garbage): bit 0 P does nothing, bit 1 I only raises its flags, bit 2 J does nothing.
-template <bool PROF, int PI = 0, int PJ = 0, int PP = 1, bool SWAP = false, bool TBF16 = true, int SKIP = 0>
-__global__ __launch_bounds__(768) void bwd_kernel_v6(BwdArgs p) {
-    LdsV6& lds = *reinterpret_cast<LdsV6*>(dyn_lds());
+// dbg (PROF): as wkv7_bwd_v6.h.  SKIP (timing experiments only, results are garbage): bit 0 P does nothing, bit 1 I only raises
+// its flags, bit 2 J does nothing.
+template <bool PROF, int PI = 0, int PJ = 0, int PP = 1, int SKIP = 0>
+__global__ __launch_bounds__(768) void bwd_kernel_v7(BwdArgs p) {
+    LdsV7& lds = *reinterpret_cast<LdsV7*>(dyn_lds());
     const int T = p.T, H = p.H;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = uniform_i32(tid >> 6);
-    const int slot = wave >> 2, w = wave & 3;            // w = index inside the role
-    const int role = SWAP && slot < 2 ? 1 - slot : slot; // role 0: I, 1: J, 2: P
+    const int role = wave >> 2, w = wave & 3;           // role 0: I, 1: J, 2: P;  w = index inside the role
     const int c16 = lane & 15, g = lane >> 4;
     const int nchunk = T / L;
     const unsigned ts = (unsigned)(H * N);
@@ -267,61 +189,56 @@ __global__ __launch_bounds__(768) void bwd_kernel_v6(BwdArgs p) {
     WKV_STAMP_DECL
     const unsigned long long rt0_ = PROF ? realtime64_() : 0ull;
 
-    if (tid < 4) lds.flag[tid] = 0u;
+    if (tid < 8) lds.flag[tid] = 0u;
+    if (role == 2 && !(SKIP & 1)) {                     // rows of the last chunk: staging + its V / dY slot
+        const DmaLane dl = dma_lane(lane, ts);
+        dma_chunk(lds, p, head_base + (size_t)(nchunk - 1) * L * ts, nchunk - 1, w, ts, dl);
+        vmem_drain();
+    }
     block_sync_lds();
 
     if (role == 2) {
         // ================================================================== P: images of chunk cp, tail of chunk cp + 3
         wave_priority<PP>();
-        RawIn raw;
         TailRaw q0{}, q1{}, q2{};                           // inputs of chunks cp+1, cp+2, cp+3 at the top of a step
-        // wave-uniform 64-bit base (SGPRs) + one 32-bit lane offset: the loads / stores take the scalar-base form and need no
-        // per-array 64-bit address arithmetic on the VALU (25 v_lshl_add_u64 per step before)
-        const unsigned lane_boff = out_off * 2u, lane_foff = out_off * 4u;
-        auto at16 = [&](const uint16_t* base, size_t uoff) { return reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(base + uoff) + lane_boff); };
-        auto fetch = [&](RawIn& r, int c) {
-            const size_t u = head_base + (size_t)c * L * ts;              // uniform
-            r.w = *at16(p.w, u); r.q = *at16(p.q, u); r.k = *at16(p.k, u); r.z = *at16(p.z, u);
-            r.a = *at16(p.a, u); r.v = *at16(p.v, u); r.dy = *at16(p.dy, u);
-            r.sa = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.sa + u) + lane_foff);
-        };
-        fetch(raw, nchunk - 1);
-        vmem_drain();
-        pin(raw);
-        // One step.  FULL (steps 3 .. nchunk-1: a tail, a prep and a non-empty S0 every time) has no conditions, so the
-        // compiler sees the same issue order on every path -- LDS-DMA, 8 prefetch loads, 5 tail stores -- and its wait for the
-        // prefetch at pin() is vmcnt(5): the DMA (older) has landed, the stores (younger) stay in flight.  A drain to
-        // vmcnt(0) there waited out the HBM write round trip in every step (the P role alone then takes 5.1k cycles per
-        // step, more than either of the other two).  The ragged first / last steps keep the full drain.
+        const unsigned lane_boff = out_off * 2u;
+        const DmaLane dl = dma_lane(lane, ts);
+        unsigned n_ps = 0;
+        // One step.  FULL (steps 3 .. nchunk-2: a tail, a prep, a non-empty S0 and a next chunk every time) has no conditions:
+        // every path issues [4-5 row DMAs, 4 S0 DMAs, 5 tail stores] in this order, so the wait before the barrier is
+        // vmcnt(5): everything the other roles will read has landed, the stores stay in flight.
         auto pstep = [&](int n, auto full_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
             const int cp = nchunk - 1 - n, cd = cp + 1, ct = cp + 3;      // images | S0 by DMA (the I waves' chunk) | tail
             WKV_STAMP(4)
             if (!(SKIP & 1)) {
+                RawP raw;
+                const bool do_prep = FULL || cp >= 0;
+                if (do_prep) {
+                    raw = read_stage(lds, la);
+                    lds_flag_add(&lds.flag[5]);             // (waits for the reads) ...
+                    n_ps += 4u;
+                    lds_flag_wait(&lds.flag[5], n_ps);      // ... all four P waves hold their pieces: the staging bytes are free
+                }
+                if (FULL || cp >= 1) dma_chunk(lds, p, head_base + (size_t)(cp - 1) * L * ts, cp - 1, w, ts, dl);
                 // S0 of chunk cd = s[cd-1] for the j-split of the next step; its buffer was last read two steps ago
                 if (FULL) dma_state(lds.s0[cd & 1], sbase + (size_t)(cd - 1) * N * N, 4 * w, 4 * w + 4, lane);
                 else if (cd >= 0 && cd <= nchunk - 1) dma_state(lds.s0[cd & 1], cd > 0 ? sbase + (size_t)(cd - 1) * N * N : nullptr, 4 * w, 4 * w + 4, lane);
-                // prefetch of the next chunk first, a full step ahead of its use (issued after the prep instead, the P role alone
-                // ran 0.77 -> 0.97 ms: when every CU streams, the loads need most of a step to come back)
-                RawIn nxt;
-                fetch(nxt, cp - 1 > 0 ? cp - 1 : 0);        // unconditional (chunk 0 again past the end): no copies, no early wait
 #if VRWKV_PDELAY
                 // the tail (VALU only) waits until the J waves have split their operands (VALU only as well): it then runs beside
                 // their matrix-core phase instead; J is active in steps 2 .. nchunk + 1 and counts 4 per step
                 if (!(SKIP & 4) && (FULL || (n >= 2 && n <= nchunk + 1))) lds_flag_wait(&lds.flag[3], 4u * (unsigned)(n - 1));
 #endif
-                if (FULL || (ct >= 0 && ct <= nchunk - 1)) tail(lds.res[ct & 1], q2, p, head_base + (size_t)ct * L * ts, lane_boff, c16, w, g, la);
+                if (FULL || (ct >= 0 && ct <= nchunk - 1)) tail7(lds, ct & 1, q2, p, head_base + (size_t)ct * L * ts, lane_boff, c16, w, g, la);
                 WKV_STAMP(0)
                 q2 = q1; q1 = q0;
-                if (FULL || cp >= 0) {
-                    const Decay dd = prep(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la);
+                if (do_prep) {
+                    const Decay dd = prep7(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la);
                     q0.q = raw.q; q0.k = raw.k; q0.z = raw.z; q0.a = raw.a;
                     q0.x2[0] = dd.x2[0]; q0.x2[1] = dd.x2[1]; q0.x2[2] = dd.x2[2]; q0.x2[3] = dd.x2[3];
                 }
                 WKV_STAMP(1)
-                if (!FULL) vmem_drain();
-                pin(nxt);
-                raw = nxt;
+                if (FULL) vmem_wait<5>(); else vmem_drain();
             }
             WKV_STAMP(2)
             block_sync_lds();
@@ -329,11 +246,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v6(BwdArgs p) {
         };
         int n = 0;
         for (; n < 3 && n < nsteps; ++n) pstep(n, BoolTag<false>{});
-        // unrolled by 6 = lcm(queue depth 3, prefetch ping-pong 2): the queue shifts and the raw <- nxt copy become renaming
-        // (120 of the ~400 VALU instructions of a step were v_mov)
-        // (unrolling this loop so that the queue shifts and `raw = nxt` become renaming was tried by 2, 3, 4 and 6: the P role's
-        // live set is at the 168-register limit of a 12-wave workgroup and every variant spilled inside the loop: 0.99 -> 1.28 ms)
-        for (; n < nchunk; ++n) pstep(n, BoolTag<true>{});
+        for (; n < nchunk - 1; ++n) pstep(n, BoolTag<true>{});
         for (; n < nsteps; ++n) pstep(n, BoolTag<false>{});
         WKV_STAMP_FLUSH(512, 10, 5)
         return;
@@ -350,24 +263,27 @@ __global__ __launch_bounds__(768) void bwd_kernel_v6(BwdArgs p) {
             const int ci = nchunk - n, cj = ci + 1;         // this role's chunk | the J waves' chunk of this step
             WKV_STAMP(4)
             if (ci >= 0 && ci <= nchunk - 1) {
-                const ChunkImg& B = lds.b[ci % 3];
-                if (!(SKIP & 2)) scores6<TBF16>(lds, B, w, c16, g, la);
+                const ChunkImg7& B = lds.b[ci % 3];
+                if (!(SKIP & 2)) wkv7v6::scores6<true>(lds, B, w, c16, g, la);
                 lds_flag_add(&lds.flag[w == 0 ? 2 : 0]);        // T has its own counter: nobody waits for it before dSA is done
                 n_sc += 3; n_t += 1;
             }
             if (w > 0 && cj >= 0 && cj <= nchunk - 1) {     // score gradients of the J waves' chunk (their dR is one step old)
-                const ChunkImg& Bj = lds.b[cj % 3];
+                const ChunkImg7& Bj = lds.b[cj % 3];
                 const uint16_t* drh = lds.dr[cj & 1][0];
                 const uint16_t* drl = lds.dr[cj & 1][1];
+                const uint16_t* vi = lds.vdy[cj & 3][0];
+                const uint16_t* dyi = lds.vdy[cj & 3][1];
                 if (!(SKIP & 2)) {
-                if (w == 1) { dscores6(lds, Bj, drh, drl, 0, c16, g, la); dscores6(lds, Bj, drh, drl, 3, c16, g, la); }
-                else dscores6(lds, Bj, drh, drl, w - 1, c16, g, la);
+                if (w == 1) { dscores7(lds, Bj.sa[0], Bj.sa[1], vi, dyi, drh, drl, 0, c16, g, la); dscores7(lds, Bj.sa[0], Bj.sa[1], vi, dyi, drh, drl, 3, c16, g, la); }
+                else dscores7(lds, Bj.sa[0], Bj.sa[1], vi, dyi, drh, drl, w - 1, c16, g, la);
                 }
                 lds_flag_add(&lds.flag[1]);
             }
             WKV_STAMP(0)
             if (!(SKIP & 2) && ci >= 0 && ci <= nchunk - 1) {
-                const ChunkImg& B = lds.b[ci % 3];
+                const ChunkImg7& B = lds.b[ci % 3];
+                const uint16_t* dyi = lds.vdy[ci & 3][1];
                 const size_t cbase = head_base + (size_t)ci * L * ts;
                 lds_flag_wait(&lds.flag[0], n_sc);
                 WKV_STAMP(1)
@@ -381,7 +297,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v6(BwdArgs p) {
                 }
                 bf16x8 sh[2], sl[2];
                 tiles_op(dSc, sh, sl);
-                const uint2 dyv = lds_read_tr16(&B.ti[1][la.trc]);               // dY[4g+e][i]
+                const uint2 dyv = lds_read_tr16(&dyi[la.trc]);                   // dY[4g+e][i]
                 const bf16x8 dyd = mk8(dyv, dyv);
                 // dSA[t][i] = sum_s M_qa[s][t] dY[s][i] + sum_j Ah[t][j] c_L[j] dS[i][j]
                 f32x4 dSA = mfma32(ld16(&lds.sc[0][la.hl]), dyd, zero4());
@@ -444,8 +360,8 @@ __global__ __launch_bounds__(768) void bwd_kernel_v6(BwdArgs p) {
             block_sync_lds();
             WKV_STAMP(3)
         }
-        WKV_STAMP_FLUSH(SWAP ? 256 : 0, 0, 5)
-        if (PROF && blockIdx.x == 0 && tid == (SWAP ? 256 : 0)) { p.dbg[15] = realtime64_() - rt0_; p.dbg[18] = tacc_[5]; p.dbg[19] = tacc_[6]; }   // i-split: dSA + dR | dV
+        WKV_STAMP_FLUSH(0, 0, 5)
+        if (PROF && blockIdx.x == 0 && tid == 0) { p.dbg[15] = realtime64_() - rt0_; p.dbg[18] = tacc_[5]; p.dbg[19] = tacc_[6]; }   // i-split: dSA + dR | dV
         return;
     }
 
@@ -461,11 +377,12 @@ __global__ __launch_bounds__(768) void bwd_kernel_v6(BwdArgs p) {
         const int cj = nchunk + 1 - n;
         WKV_STAMP(4)
         if (!(SKIP & 4) && cj >= 0 && cj <= nchunk - 1) {
-            const ChunkImg& B = lds.b[cj % 3];
+            const ChunkImg7& B = lds.b[cj % 3];
             const uint16_t* drh = lds.dr[cj & 1][0];
             const uint16_t* drl = lds.dr[cj & 1][1];
+            const uint16_t* vi = lds.vdy[cj & 3][0];
+            const uint16_t* dyi = lds.vdy[cj & 3][1];
             const float* s0img = lds.s0[cj & 1];
-            ResImg& R = lds.res[cj & 1];
             n_dm += 3;
             // ---------------------------------------------------------------- j-split (j = 16w + c16)
             f32x4 dZt, dQt, dAh, dKh;
@@ -494,14 +411,14 @@ __global__ __launch_bounds__(768) void bwd_kernel_v6(BwdArgs p) {
                     dZt = mfma32(s0h[0], drr, zero4());                                  // dR S0
                     dZt = mfma32(s0l[0], drr, dZt);
                     dZt = mfma32(s0h[0], ld16(&drl[la.row[0]]), dZt);
-                    const bf16x8 dyr = ld16(&B.ti[1][la.row[0]]);
+                    const bf16x8 dyr = ld16(&dyi[la.row[0]]);
                     dQt = mfma32(s0h[0], dyr, zero4());                                  // dY S0
                     dQt = mfma32(s0l[0], dyr, dQt);
-                    const bf16x8 sah = ld16(&B.ti[2][la.row[0]]);
+                    const bf16x8 sah = ld16(&B.sa[0][la.row[0]]);
                     dAh = mfma32(duh[0], sah, zero4());                                  // SA dU
                     dAh = mfma32(dul[0], sah, dAh);
-                    dAh = mfma32(duh[0], ld16(&B.ti[3][la.row[0]]), dAh);
-                    const bf16x8 vr = ld16(&B.ti[0][la.row[0]]);
+                    dAh = mfma32(duh[0], ld16(&B.sa[1][la.row[0]]), dAh);
+                    const bf16x8 vr = ld16(&vi[la.row[0]]);
                     dKh = mfma32(duh[0], vr, zero4());                                   // V dU
                     dKh = mfma32(dul[0], vr, dKh);
                 }
@@ -510,14 +427,14 @@ __global__ __launch_bounds__(768) void bwd_kernel_v6(BwdArgs p) {
                     dZt = mfma32(s0h[1], drr, dZt);
                     dZt = mfma32(s0l[1], drr, dZt);
                     dZt = mfma32(s0h[1], ld16(&drl[la.row[1]]), dZt);
-                    const bf16x8 dyr = ld16(&B.ti[1][la.row[1]]);
+                    const bf16x8 dyr = ld16(&dyi[la.row[1]]);
                     dQt = mfma32(s0h[1], dyr, dQt);
                     dQt = mfma32(s0l[1], dyr, dQt);
-                    const bf16x8 sah = ld16(&B.ti[2][la.row[1]]);
+                    const bf16x8 sah = ld16(&B.sa[0][la.row[1]]);
                     dAh = mfma32(duh[1], sah, dAh);
                     dAh = mfma32(dul[1], sah, dAh);
-                    dAh = mfma32(duh[1], ld16(&B.ti[3][la.row[1]]), dAh);
-                    const bf16x8 vr = ld16(&B.ti[0][la.row[1]]);
+                    dAh = mfma32(duh[1], ld16(&B.sa[1][la.row[1]]), dAh);
+                    const bf16x8 vr = ld16(&vi[la.row[1]]);
                     dKh = mfma32(duh[1], vr, dKh);
                     dKh = mfma32(dul[1], vr, dKh);
                 }
@@ -531,7 +448,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v6(BwdArgs p) {
 #pragma unroll
                 for (int ib = 0; ib < 4; ++ib) {
                     const int o = la.tri[ib >> 1] + 4 * (ib & 1);
-                    const bf16x8 x8 = mk8(lds_read_tr16(&B.ti[1][o]), lds_read_tr16(&drh[o]));
+                    const bf16x8 x8 = mk8(lds_read_tr16(&dyi[o]), lds_read_tr16(&drh[o]));
                     // [dR_l^T | finite filler]: the filler meets the zero half of zpad (another tile's dR_l: finite, not reused)
                     const bf16x8 xl8 = mk8(lds_read_tr16(&drl[o]), lds_read_tr16(&drl[o ^ 4]));
                     f32x4 acc = dU[ib];
@@ -544,7 +461,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v6(BwdArgs p) {
                 }
                 gl += lane_xor16(gl);
                 gl += lane_xor32(gl);
-                if (g == 0) R.glast[j] = gl_carry;          // the term of THIS chunk was formed a step ago
+                if (g == 0) lds.glast[cj & 1][j] = gl_carry;          // the term of THIS chunk was formed a step ago
                 gl_carry = gl;
             }
             WKV_STAMP(0)
@@ -578,18 +495,20 @@ __global__ __launch_bounds__(768) void bwd_kernel_v6(BwdArgs p) {
                     dKh = mfma32(qzh, mk8(lds_read_tr16(&lds.dsc[3][la.hlt + 4]), lds_read_tr16(&lds.dsc[1][la.hlt + 4])), dKh);
                 }
             }
-            // results: lane = token c16, registers = channels 16w + 4g + e -> fp32 images for the P waves' tail
-            *reinterpret_cast<float4*>(&R.r[0][la.f32]) = make_float4(dZt[0], dZt[1], dZt[2], dZt[3]);
-            *reinterpret_cast<float4*>(&R.r[1][la.f32]) = make_float4(dQt[0], dQt[1], dQt[2], dQt[3]);
-            *reinterpret_cast<float4*>(&R.r[2][la.f32]) = make_float4(dAh[0], dAh[1], dAh[2], dAh[3]);
-            *reinterpret_cast<float4*>(&R.r[3][la.f32]) = make_float4(dKh[0], dKh[1], dKh[2], dKh[3]);
+            // results: lane = token c16, registers = channels 16w + 4g + e -> the fp32 image of the P waves' tail, once the tail of
+            // the chunk before (this step's, steps 3 ..) has read it: 4 P waves per tail
+            if (!(SKIP & 1) && n >= 3) lds_flag_wait(&lds.flag[4], 4u * (unsigned)(n - 2));
+            *reinterpret_cast<float4*>(&lds.res[0][la.f32]) = make_float4(dZt[0], dZt[1], dZt[2], dZt[3]);
+            *reinterpret_cast<float4*>(&lds.res[1][la.f32]) = make_float4(dQt[0], dQt[1], dQt[2], dQt[3]);
+            *reinterpret_cast<float4*>(&lds.res[2][la.f32]) = make_float4(dAh[0], dAh[1], dAh[2], dAh[3]);
+            *reinterpret_cast<float4*>(&lds.res[3][la.f32]) = make_float4(dKh[0], dKh[1], dKh[2], dKh[3]);
         }
         WKV_STAMP(2)
         block_sync_lds();
         WKV_STAMP(3)
     }
-    WKV_STAMP_FLUSH(SWAP ? 0 : 256, 5, 5)
-    if (PROF && blockIdx.x == 0 && tid == (SWAP ? 0 : 256)) { p.dbg[16] = tacc_[5]; p.dbg[17] = tacc_[6]; }   // j-split: operand split | output products
+    WKV_STAMP_FLUSH(256, 5, 5)
+    if (PROF && blockIdx.x == 0 && tid == 256) { p.dbg[16] = tacc_[5]; p.dbg[17] = tacc_[6]; }   // j-split: operand split | output products
 }
 
-}  // namespace wkv7v6
+}  // namespace wkv7v7

@@ -1,0 +1,486 @@
+// WKV7 backward, chunked MFMA form, fifth-generation schedule -- gfx950.
+//
+// Same math as wkv7_bwd_v5.h (reference: VisualRWKV-v7/v7.00/cuda/wkv7_cuda.cu:54-130), the three roles and the full-row
+// LDS-DMA memory role of wkv7_bwd_v7.h.  The phase stamps of v6 / v7 (profiles/r4_wkv7_phases_b16.json) show every role stretched
+// by the other two on its SIMD -- the J waves' 130-instruction operand split takes 1.2-2.2k cycles beside the P waves, their 20
+// output MFMAs 1.2-2k -- with the VALU port ~60 % busy (profiles/r3_wkv7_pmc_b16.txt: 273 M VALU instructions, 4.1 cycles
+// each) and the J role and I wave 0 (scores + T chain, THEN its i-split) last at the barrier.  Three changes take work off
+// those two:
+//   * ONE copy of dL/dS.  v5 - v7 keep dS twice (i-split tiles in the I waves, j-split tiles in the J waves: the tile-level
+//     analogue of the reference's dstate / dstateT pair) and update both: 2 x 12 MFMAs, 2 x 64 VALU of scaling and hi/lo splits
+//     per wave pair and step.  Here only the I waves hold dS.  They already form hi/lo operands of diag(c_L) dS^T for dSA / dV;
+//     those 8 registers x 2 go to a [i][j] bf16 image (4 x ds_write_b128 per lane), and the J waves -- one step later --
+//     fetch THEIR operands of the same matrix (k = i along the image's rows) with ds_read_b64_tr_b16: no second accumulator,
+//     no second split, no second update.  The decay-gradient term sum_i dS[i][j] S_L[i][j] becomes the diagonal of
+//     (c_L dS)^T S_L / c_L: 6 MFMAs on operands the J waves hold anyway (the S0 operands of the previous step).
+//   * The T chain ((I - M_za)^-1 by nilpotent doubling: 28 dependent MFMA / split stages) runs on P wave 0, which has >2k
+//     cycles of slack per step in v7 and whose registers the DMA memory role freed; it only needs the images the P waves built
+//     a step earlier.  The four I waves share the seven score / score-gradient pieces and all start their i-split at once.
+//   * S0 is single buffered (the P waves request the next one when the J waves have lifted theirs into registers: the same
+//     counter that releases the tail), which pays for the dS image: LDS 157 KB.
+#pragma once
+#include <gfx950_prims.h>
+#include <wkv7_chunked.h>
+#include <wkv7_bwd_v7.h>     // ChunkImg7, RawP, DmaLane, dma_lane, prep7, dscores-style helpers; through it v6 / v5 building blocks
+
+namespace wkv7v8 {
+
+using wkv7::BwdArgs;
+using namespace wkv7c;
+using namespace wkv7v5;      // IMG, HLI, img_off, f32_off, LaneAddr, lane_addr, ld16, st16, mfma32, dot64, mask_split, tiles_op, dma_state
+using wkv7v6::Decay;
+using wkv7v6::decay_scan;
+using wkv7v6::TailRaw;
+using wkv7v6::BoolTag;
+
+using wkv7v7::ChunkImg7;
+using wkv7v7::RawP;
+using wkv7v7::DmaLane;
+using wkv7v7::dma_lane;
+using wkv7v7::prep7;
+using wkv7v7::dma_chunk;
+using wkv7v7::read_stage;
+using wkv7v7::tail7;
+using wkv7v7::dscores7;
+constexpr int SIMG = N * N;           // elements of a [64][64] image
+struct LdsV8 {
+    ChunkImg7 b[3];
+    uint16_t vdy[4][2][IMG];         // V, dY [t][i] of chunk c in slot c & 3, written by LDS-DMA (swizzled like every image)
+    uint16_t stg[5][IMG];            // w q k z a of the chunk the P waves prepare next (LDS-DMA; read by the P waves only)
+    float stg_sa[IMG];               // sa of that chunk, fp32, f32_off swizzle
+    uint16_t dz[2][IMG];             // "DZ" images of M_zk and T^T (I waves, same step)
+    uint16_t sc[2][HLI];             // M_qa, M_qk pair images (I waves, same step)
+    uint16_t dsc[4][HLI];            // score gradients of the J waves' chunk (I waves 1-3 -> J waves, same step)
+    uint16_t dr[2][2][IMG];          // dR hi, lo [t][i] by chunk parity (I waves -> next step's dM and j-split)
+    float s0[N * N];                 // S0 of the J waves' next chunk (P waves' LDS-DMA, requested when flag 3 says the current one is in registers)
+    uint16_t dsi[2][SIMG];           // hi, lo of diag(c_L) dS as the I waves hold it at the start of their step: [i][j] bf16, swizzled like
+                                     // every image (I waves -> the J waves' operands one step later; flag 3 hands it back)
+    float res[4][IMG];               // J -> P: dZt dQt dAh dKh before the decay factors, fp32 (single: flag 4 hands it back)
+    float glast[2][N];               // sum_i dS_L[i][j] S_L[i][j] at the chunk's last token, by chunk parity
+    unsigned flag[8];                // 0: M_qa, M_qk, M_zk written (3 per step)  1: dM written (3)  2: T written (1)  3: J operands split (4)
+                                     // 4: tail has read `res` (4)  5: P waves hold their staging pieces (4)
+};
+static_assert(sizeof(LdsV8) <= 160 * 1024, "LDS budget");
+
+// ------------------------------------------------------------------------------------------ P waves 1-3: lean request issue
+// The steady-state steps issue their requests with the scalar-base form and NO per-request address arithmetic: the array base
+// pointers (kernel arguments) are the scalar bases, the chunk's byte offset is added once per step to three or four per-lane
+// offset registers, and the 16 x 1 KB of S0 use four loop-invariant lane offsets + the instruction's immediate.  (The generic
+// dma_chunk / dma_state cost ~8-10 scalar and vector instructions per request -- pointer selects, 64-bit adds, M0 save / restore --
+// and every instruction of any class takes an issue slot: profiles/r4_wkv7_pmc_v6_v8.txt.)  Offsets are 32-bit: the launcher
+// sends tensors of 4 GiB and more to wkv7_bwd_v6.h.
+struct LeanLane { unsigned b16, b16h, sa0, sa1, vs[4]; };
+DEVFN LeanLane lean_lane(int lane, int wi, unsigned ts) {
+    const DmaLane dl = dma_lane(lane, ts);
+    LeanLane ll;
+    ll.b16 = dl.b16; ll.b16h = dl.b16 + 8u * ts * 2u;
+    const unsigned qa = wi == 0 ? 1u : wi == 1 ? 2u : 0u;             // the sa quarters of this wave: i = wi + 3k in {14 .. 17}
+    ll.sa0 = (dl.f32 ^ (64u * qa)) + qa * 4u * ts * 4u;
+    ll.sa1 = (dl.f32 ^ (64u * 3u)) + 3u * 4u * ts * 4u;               // wave 3 (wi = 2) also has quarter 3
+    const unsigned r4 = (unsigned)lane >> 4, base = r4 * 256u + 16u * (((unsigned)lane & 15u) ^ r4);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) ll.vs[m] = base ^ (64u * (unsigned)m);          // row 4k + r4 of the S0 image: source slot ^ (row & 15)
+    return ll;
+}
+template <int WI>
+DEVFN void rows_lean(LdsV8& lds, const BwdArgs& p, int c, unsigned cb16, const LeanLane& ll) {
+    const unsigned v16 = ll.b16 + cb16, v16h = ll.b16h + cb16, vsa0 = ll.sa0 + 2u * cb16, vsa1 = ll.sa1 + 2u * cb16;
+    const unsigned vd = lds_addr_u32(lds.vdy[c & 3][0]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int i = WI + 3 * k;                          // compile-time after unrolling
+        if (i < 14) {
+            const int arr = i >> 1, half = i & 1;
+            const uint16_t* src = arr == 0 ? p.w : arr == 1 ? p.q : arr == 2 ? p.k : arr == 3 ? p.z : arr == 4 ? p.a : arr == 5 ? p.v : p.dy;
+            const unsigned dst = (arr < 5 ? lds_addr_u32(lds.stg[arr]) : vd + (unsigned)(arr - 5) * IMG * 2u) + (unsigned)half * 8u * N * 2u;
+            lds_dma16_lean<0>(src, half ? v16h : v16, dst);
+        } else {
+            const int qd = i - 14;
+            lds_dma16_lean<0>(p.sa, (WI == 2 && qd == 3) ? vsa1 : vsa0, lds_addr_u32(lds.stg_sa) + (unsigned)qd * 4u * N * 4u);
+        }
+    }
+}
+template <int WI>
+DEVFN void s0_lean(LdsV8& lds, const float* s_chunk, const LeanLane& ll) {
+    constexpr int K0 = WI == 0 ? 0 : WI == 1 ? 5 : 10, K1 = WI == 0 ? 5 : WI == 1 ? 10 : 16;
+    const unsigned dst = lds_addr_u32(lds.s0);
+#pragma unroll
+    for (int k = K0; k < K1; ++k) {
+        const char* base = reinterpret_cast<const char*>(s_chunk) + (k >> 2) * 4096;
+        const unsigned d = dst + (unsigned)(k >> 2) * 4096u;      // the instruction's immediate offset moves the LDS address as well
+        switch (k & 3) {
+            case 0: lds_dma16_lean<0>(base, ll.vs[0], d); break;
+            case 1: lds_dma16_lean<1024>(base, ll.vs[1], d); break;
+            case 2: lds_dma16_lean<2048>(base, ll.vs[2], d); break;
+            default: lds_dma16_lean<3072>(base, ll.vs[3], d); break;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ kernel
+// dbg (PROF): as wkv7_bwd_v6.h.  SKIP (timing experiments only, results are garbage): bit 0 P does nothing, bit 1 I only raises
+// its flags, bit 2 J does nothing.
+// TBF16: the doubling chain of T on the bf16 matrix core with split operands (2 MFMAs + 2 splits per product) or on the f32 one (4 MFMAs of
+// twice the pipe time, no VALU work)
+// PT: priority of P wave 0 while it runs the T chain (back to PP afterwards)
+template <bool PROF, int PI = 0, int PJ = 0, int PP = 1, int SKIP = 0, bool TBF16 = true, int PT = PP>
+__global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
+    LdsV8& lds = *reinterpret_cast<LdsV8*>(dyn_lds());
+    const int T = p.T, H = p.H;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = uniform_i32(tid >> 6);
+    const int role = wave >> 2, w = wave & 3;           // role 0: I, 1: J, 2: P;  w = index inside the role
+    const int c16 = lane & 15, g = lane >> 4;
+    const int nchunk = T / L;
+    const unsigned ts = (unsigned)(H * N);
+    const unsigned bh = blockIdx.x;
+    const size_t head_base = ((size_t)(bh / H) * T * H + (bh % H)) * N;
+    const float* sbase = p.s + (size_t)bh * nchunk * N * N;
+    const int nsteps = nchunk + 3;
+    const LaneAddr la = lane_addr(c16, g, w);
+    const unsigned out_off = (unsigned)c16 * ts + 16u * w + 4u * g;        // token c16, channels 16w+4g..+3
+    WKV_STAMP_DECL
+    const unsigned long long rt0_ = PROF ? realtime64_() : 0ull;
+
+    if (tid < 8) lds.flag[tid] = 0u;
+    if (role == 2 && !(SKIP & 1)) {                     // rows of the last chunk: staging + its V / dY slot
+        const DmaLane dl = dma_lane(lane, ts);
+        dma_chunk(lds, p, head_base + (size_t)(nchunk - 1) * L * ts, nchunk - 1, w, ts, dl);
+        vmem_drain();
+    }
+    block_sync_lds();
+
+    if (role == 2) {
+        // ================================================================== P: images of chunk cp, T of chunk cp + 1, tail of chunk cp + 3
+        wave_priority<PP>();
+        TailRaw q0{}, q1{}, q2{};                           // inputs of chunks cp+1, cp+2, cp+3 at the top of a step
+        const unsigned lane_boff = out_off * 2u;
+        const DmaLane dl = dma_lane(lane, ts);
+        const LeanLane ll = lean_lane(lane, w > 0 ? w - 1 : 0, ts);
+        unsigned n_ps = 0;
+        // One step.  FULL (steps 3 .. nchunk-2: a tail, a prep, a T, a non-empty S0 and a next chunk every time) has no
+        // conditions: every path issues [6 row DMAs, 5-6 S0 DMAs (waves 1-3), 5 tail stores] in this order, so the wait before the
+        // barrier is vmcnt(5): everything the other roles will read has landed, the stores stay in flight.
+        auto pstep = [&](int n, auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            const int cp = nchunk - 1 - n, cd = cp + 1, ct = cp + 3;      // images | the I waves' chunk: T now, S0 for the J waves' next step | tail
+            WKV_STAMP(4)
+            if (!(SKIP & 1)) {
+                RawP raw;
+                const bool do_prep = FULL || cp >= 0;
+                if (do_prep) {
+                    raw = read_stage(lds, la);
+                    lds_flag_add(&lds.flag[5]);             // (waits for the reads) ...
+                    n_ps += 4u;
+                    if (w > 0) lds_flag_wait(&lds.flag[5], n_ps);      // ... all four P waves hold their pieces: the staging bytes are free
+                }
+                // waves 1-3 request the rows of the next chunk (6 instructions each); wave 0 has the T chain instead
+                if (FULL) {
+                    const unsigned cb16 = (unsigned)((head_base + (size_t)(cp - 1) * L * ts) * 2u);
+                    if (w == 1) rows_lean<0>(lds, p, cp - 1, cb16, ll); else if (w == 2) rows_lean<1>(lds, p, cp - 1, cb16, ll);
+                    else if (w == 3) rows_lean<2>(lds, p, cp - 1, cb16, ll);
+                } else if (w > 0 && cp >= 1) dma_chunk<LdsV8, 3>(lds, p, head_base + (size_t)(cp - 1) * L * ts, cp - 1, w - 1, ts, dl);
+                // T = (I - M_za)^-1 of the I waves' chunk, from the images this role built a step ago: the doubling chain is 28
+                // dependent MFMA / split stages and nobody needs T before the I waves have formed dSA
+                if (w == 0 && (FULL || (cd >= 0 && cd <= nchunk - 1))) {
+                    if (PT != PP) wave_priority<PT>();
+                    wkv7v6::scores6<TBF16, LdsV8, ChunkImg7, true>(lds, lds.b[cd % 3], 0, c16, g, la);
+                    lds_flag_add(&lds.flag[2]);
+                    if (PT != PP) wave_priority<PP>();
+                }
+                // the J waves have lifted S0 and their dS operands into registers (and split them: VALU only, like the tail, which
+                // therefore runs beside their matrix-core phase); J is active in steps 2 .. nchunk + 1 and counts 4 per step
+                if (!(SKIP & 4) && (FULL || (n >= 2 && n <= nchunk + 1))) lds_flag_wait(&lds.flag[3], 4u * (unsigned)(n - 1));
+                // S0 of chunk cd = s[cd-1] for the j-split of the next step, into the image the J waves have just left
+                {
+                    const int k0 = w == 1 ? 0 : w == 2 ? 5 : 10, k1 = w == 0 ? 0 : w == 1 ? 5 : w == 2 ? 10 : 16;      // waves 1-3: 5 5 6 KB
+                    if (FULL) {
+                        const float* sc = sbase + (size_t)(cd - 1) * N * N;
+                        if (w == 1) s0_lean<0>(lds, sc, ll); else if (w == 2) s0_lean<1>(lds, sc, ll); else if (w == 3) s0_lean<2>(lds, sc, ll);
+                    } else if (cd >= 0 && cd <= nchunk - 1) dma_state(lds.s0, cd > 0 ? sbase + (size_t)(cd - 1) * N * N : nullptr, k0, k1, lane);
+                }
+                if (FULL || (ct >= 0 && ct <= nchunk - 1)) tail7(lds, ct & 1, q2, p, head_base + (size_t)ct * L * ts, lane_boff, c16, w, g, la);
+                WKV_STAMP(0)
+                q2 = q1; q1 = q0;
+                if (do_prep) {
+                    const Decay dd = prep7(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la);
+                    q0.q = raw.q; q0.k = raw.k; q0.z = raw.z; q0.a = raw.a;
+                    q0.x2[0] = dd.x2[0]; q0.x2[1] = dd.x2[1]; q0.x2[2] = dd.x2[2]; q0.x2[3] = dd.x2[3];
+                }
+                WKV_STAMP(1)
+                if (FULL) vmem_wait<5>(); else vmem_drain();
+            } else if (w == 0 && cd >= 0 && cd <= nchunk - 1) lds_flag_add(&lds.flag[2]);
+            WKV_STAMP(2)
+            block_sync_lds();
+            WKV_STAMP(3)
+        };
+        int n = 0;
+        for (; n < 3 && n < nsteps; ++n) pstep(n, BoolTag<false>{});
+        for (; n < nchunk - 1; ++n) pstep(n, BoolTag<true>{});
+        for (; n < nsteps; ++n) pstep(n, BoolTag<false>{});
+        WKV_STAMP_FLUSH(512, 10, 5)
+        return;
+    }
+
+    if (role == 0) {
+        // ================================================================== I: chunk ci = nchunk - n  (steps 1 .. nchunk)
+        wave_priority<PI>();
+        f32x4 dS1[4];                                       // dS1[jb][r] = dS[i = 16w+c16][j = tix(jb, 4g+r)]: the only copy of dL/dS
+#pragma unroll
+        for (int x = 0; x < 4; ++x) dS1[x] = zero4();
+        unsigned n_sc = 0, n_t = 0;
+        const int img_row = img_off(16 * w + c16, 8 * g);   // this lane's 16-byte piece of the dS image, k block 0 (+ 32 columns: block 1)
+        const int img_row1 = img_off(16 * w + c16, 32 + 8 * g);
+        for (int n = 0; n < nsteps; ++n) {
+            const int ci = nchunk - n, cj = ci + 1;         // this role's chunk | the J waves' chunk of this step
+            WKV_STAMP(4)
+            // the seven score / score-gradient pieces go to waves 1-3: wave 0 shares its SIMD with the T chain (P wave 0).
+            //   wave 1: M_qa, dM_za   wave 2: M_qk, dM_zk, dM_qk   wave 3: M_zk, dM_qa      (12 / 12 / 10 MFMAs)
+            if (ci >= 0 && ci <= nchunk - 1) {
+                if (w > 0) {
+                    if (!(SKIP & 2)) wkv7v6::scores6<true>(lds, lds.b[ci % 3], w, c16, g, la);
+                    lds_flag_add(&lds.flag[0]);
+                }
+                n_sc += 3; n_t += 1;
+            }
+            if (w > 0 && cj >= 0 && cj <= nchunk - 1) {     // score gradients of the J waves' chunk (their dR is one step old)
+                const ChunkImg7& Bj = lds.b[cj % 3];
+                const uint16_t *vi = lds.vdy[cj & 3][0], *dyi = lds.vdy[cj & 3][1], *drh = lds.dr[cj & 1][0], *drl = lds.dr[cj & 1][1];
+                if (!(SKIP & 2)) {
+                    dscores7(lds, Bj.sa[0], Bj.sa[1], vi, dyi, drh, drl, w == 3 ? 2 : w - 1, c16, g, la);
+                    if (w == 2) dscores7(lds, Bj.sa[0], Bj.sa[1], vi, dyi, drh, drl, 3, c16, g, la);
+                }
+                lds_flag_add(&lds.flag[1]);
+            }
+            WKV_STAMP(0)
+            if (!(SKIP & 2) && ci >= 0 && ci <= nchunk - 1) {
+                const ChunkImg7& B = lds.b[ci % 3];
+                const uint16_t* dyi = lds.vdy[ci & 3][1];
+                const size_t cbase = head_base + (size_t)ci * L * ts;
+                // ------------------------------------------------------------ i-split (i = 16w + c16)
+                f32x4 dSc[4];                               // diag(c_L) dS^T: operand of dSA / dV, start of the update, and the J waves' dU
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    const float4 cl = *reinterpret_cast<const float4*>(&B.cl[tix(jb, 4 * g)]);
+                    dSc[jb] = dS1[jb];
+                    dSc[jb][0] *= cl.x; dSc[jb][1] *= cl.y; dSc[jb][2] *= cl.z; dSc[jb][3] *= cl.w;
+                }
+                bf16x8 sh[2], sl[2];
+                tiles_op(dSc, sh, sl);
+                // the same operands, one step later, for the J waves: lane (i, g) holds columns j = 32 kb + 8g .. +7 of row i.  The J
+                // waves took their operands of the previous image at the top of this step (flag 3; J is active in steps 2 .. nchunk+1)
+                if (!(SKIP & 4) && n >= 2 && n <= nchunk + 1) lds_flag_wait(&lds.flag[3], 4u * (unsigned)(n - 1));
+                *reinterpret_cast<bf16x8*>(&lds.dsi[0][img_row]) = sh[0]; *reinterpret_cast<bf16x8*>(&lds.dsi[0][img_row1]) = sh[1];
+                *reinterpret_cast<bf16x8*>(&lds.dsi[1][img_row]) = sl[0]; *reinterpret_cast<bf16x8*>(&lds.dsi[1][img_row1]) = sl[1];
+                lds_flag_wait(&lds.flag[0], n_sc);
+                WKV_STAMP(1)
+                const uint2 dyv = lds_read_tr16(&dyi[la.trc]);                   // dY[4g+e][i]
+                const bf16x8 dyd = mk8(dyv, dyv);
+                // dSA[t][i] = sum_s M_qa[s][t] dY[s][i] + sum_j Ah[t][j] c_L[j] dS[i][j]
+                f32x4 dSA = mfma32(ld16(&lds.sc[0][la.hl]), dyd, zero4());
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const bf16x8 ah = ld16(&B.opnd[4][la.row[kb]]);
+                    dSA = mfma32(ah, sh[kb], dSA);
+                    dSA = mfma32(ah, sl[kb], dSA);
+                    dSA = mfma32(ld16(&B.opnd[5][la.row[kb]]), sh[kb], dSA);
+                }
+                uint2 xh, xl, rh, rl;
+                split4(dSA, xh, xl);
+                const bf16x8 xhl = mk8(xh, xl);
+                // dR = T^T dSA in both orientations: [t][i] stays in registers, [i][t] (token per lane) goes to LDS
+                lds_flag_wait(&lds.flag[2], n_t);               // T of this chunk (P wave 0's doubling chain) is in LDS
+                const bf16x8 t1 = ld16(&lds.dz[1][la.row[0]]), t2 = ld16(&lds.dz[1][la.row[1]]);        // [T_h T_h], [T_l 0]
+                f32x4 dR = mfma32(t1, xhl, zero4());
+                dR = mfma32(t2, xhl, dR);
+                f32x4 dRT = mfma32(xhl, t1, zero4());
+                dRT = mfma32(xhl, t2, dRT);
+                split4(dR, rh, rl);
+                {
+                    uint2 th, tl;
+                    split4(dRT, th, tl);
+                    st8(&lds.dr[ci & 1][0][la.own], th);
+                    st8(&lds.dr[ci & 1][1][la.own], tl);
+                }
+                WKV_STAMP(5)
+                // dV^T[i][t] = sum_j c_L[j] dS[i][j] Kh[t][j] + sum_s dY[s][i] M_qk[s][t] + sum_s dR[s][i] M_zk[s][t]
+                {
+                    f32x4 dV = mfma32(dyd, ld16(&lds.sc[1][la.hl]), zero4());
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        const bf16x8 kh = ld16(&B.opnd[6][la.row[kb]]);
+                        dV = mfma32(sh[kb], kh, dV);
+                        dV = mfma32(sl[kb], kh, dV);
+                        dV = mfma32(sh[kb], ld16(&B.opnd[7][la.row[kb]]), dV);
+                    }
+                    const bf16x8 rhl = mk8(rh, rl);
+                    dV = mfma32(rhl, ld16(&lds.dz[0][la.row[0]]), dV);                 // [M_zk_h M_zk_h]
+                    dV = mfma32(rhl, ld16(&lds.dz[0][la.row[1]]), dV);                 // [M_zk_l 0]
+                    *reinterpret_cast<uint2*>(p.dv + cbase + out_off) = make_uint2(cvt_pk_bf16(dV[0], dV[1]), cvt_pk_bf16(dV[2], dV[3]));
+                }
+                WKV_STAMP(6)
+                // dS^T <- diag(c_L) dS^T + [Qt^T | Zt^T] [dY ; dR]
+                const bf16x8 y1 = mk8(dyv, rh), y2 = mk8(0u, 0u, rl.x, rl.y);
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    f32x4 acc = dSc[jb];
+                    const int o = la.tri[jb >> 1] + 4 * (jb & 1);
+                    const bf16x8 xh8 = mk8(lds_read_tr16(&B.opnd[2][o]), lds_read_tr16(&B.opnd[0][o]));
+                    const bf16x8 xl8 = mk8(lds_read_tr16(&B.opnd[3][o]), lds_read_tr16(&B.opnd[1][o]));
+                    acc = mfma32(xh8, y1, acc);
+                    acc = mfma32(xl8, y1, acc);
+                    acc = mfma32(xh8, y2, acc);
+                    dS1[jb] = acc;
+                }
+            }
+            WKV_STAMP(2)
+            block_sync_lds();
+            WKV_STAMP(3)
+        }
+        WKV_STAMP_FLUSH(0, 0, 5)
+        if (PROF && blockIdx.x == 0 && tid == 0) { p.dbg[15] = realtime64_() - rt0_; p.dbg[18] = tacc_[5]; p.dbg[19] = tacc_[6]; }   // i-split: dSA + dR | dV
+        return;
+    }
+
+    // ====================================================================== J: chunk cj = nchunk + 1 - n  (steps 2 .. nchunk + 1)
+    wave_priority<PJ>();
+    const int j = 16 * w + c16;                         // key column of the j-split tiles
+    // transposing reads of the dS image: operand rows j = 16w + c16, k = i = 32 kb + 8g + e: rows 32 kb + 8g + 4h + (c16 >> 2)
+    int tro[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) tro[kb][h] = img_off(32 * kb + 8 * g + 4 * h + (c16 >> 2), 16 * w + 4 * (c16 & 3));
+    bf16x8 s0h_p[2] = {mk8(0u, 0u, 0u, 0u), mk8(0u, 0u, 0u, 0u)}, s0l_p[2] = {mk8(0u, 0u, 0u, 0u), mk8(0u, 0u, 0u, 0u)};   // S0 operands of the previous step = S_L of this one
+    unsigned n_dm = 0;
+    for (int n = 0; n < nsteps; ++n) {
+        const int cj = nchunk + 1 - n;
+        WKV_STAMP(4)
+        if (!(SKIP & 4) && cj >= 0 && cj <= nchunk - 1) {
+            const ChunkImg7& B = lds.b[cj % 3];
+            const uint16_t* drh = lds.dr[cj & 1][0];
+            const uint16_t* drl = lds.dr[cj & 1][1];
+            const uint16_t* vi = lds.vdy[cj & 3][0];
+            const uint16_t* dyi = lds.vdy[cj & 3][1];
+            n_dm += 3;
+            // ---------------------------------------------------------------- j-split (j = 16w + c16)
+            f32x4 dZt, dQt, dAh, dKh;
+            {
+                const float clj = B.cl[j];
+                f32x4 S0[4];
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) {
+                    // [ib][r] = S0[i = tix(ib, 4g+r)][j]  <-  image row j (zeros for the first chunk of the sequence)
+                    const float4 x = *reinterpret_cast<const float4*>(&lds.s0[f32_off(j, tix(ib, 4 * g))]);
+                    S0[ib][0] = x.x; S0[ib][1] = x.y; S0[ib][2] = x.z; S0[ib][3] = x.w;
+                }
+                // dU = dS diag(c_L) as the I waves split it a step ago: [duh | dul][kb] = rows j, k = i = 32 kb + 8g + e
+                bf16x8 duh[2], dul[2];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    duh[kb] = mk8(lds_read_tr16(&lds.dsi[0][tro[kb][0]]), lds_read_tr16(&lds.dsi[0][tro[kb][1]]));
+                    dul[kb] = mk8(lds_read_tr16(&lds.dsi[1][tro[kb][0]]), lds_read_tr16(&lds.dsi[1][tro[kb][1]]));
+                }
+                bf16x8 s0h[2], s0l[2];
+                tiles_op(S0, s0h, s0l);
+                lds_flag_add(&lds.flag[3]);                 // (waits for the reads) S0 and the dS image may be overwritten
+                WKV_STAMP(5)
+                // decay-gradient term of this chunk: sum_i dS[i][j] S_L[i][j] = diag((dU)^T S_L)[j] / c_L[j], S_L = the S0 of a step ago
+                {
+                    f32x4 G = mfma32(duh[0], s0h_p[0], zero4());
+                    G = mfma32(dul[0], s0h_p[0], G);
+                    G = mfma32(duh[0], s0l_p[0], G);
+                    G = mfma32(duh[1], s0h_p[1], G);
+                    G = mfma32(dul[1], s0h_p[1], G);
+                    G = mfma32(duh[1], s0l_p[1], G);
+                    // G[r] = (m = 4g + r, n = c16): the diagonal element of column c16 sits in lane group g == c16 >> 2, register c16 & 3
+                    const int r = c16 & 3;
+                    const float d01 = r & 1 ? G[1] : G[0], d23 = r & 1 ? G[3] : G[2];
+                    if ((c16 >> 2) == g) lds.glast[cj & 1][j] = (r & 2 ? d23 : d01) * fast_rcp(clj);
+                }
+                // transposed results: D[m = j][n = t]  (lane = token, registers = 4 consecutive channels of the wave's 16)
+                {
+                    const bf16x8 drr = ld16(&drh[la.row[0]]);
+                    dZt = mfma32(s0h[0], drr, zero4());                                  // dR S0
+                    dZt = mfma32(s0l[0], drr, dZt);
+                    dZt = mfma32(s0h[0], ld16(&drl[la.row[0]]), dZt);
+                    const bf16x8 dyr = ld16(&dyi[la.row[0]]);
+                    dQt = mfma32(s0h[0], dyr, zero4());                                  // dY S0
+                    dQt = mfma32(s0l[0], dyr, dQt);
+                    const bf16x8 sah = ld16(&B.sa[0][la.row[0]]);
+                    dAh = mfma32(duh[0], sah, zero4());                                  // SA dU
+                    dAh = mfma32(dul[0], sah, dAh);
+                    dAh = mfma32(duh[0], ld16(&B.sa[1][la.row[0]]), dAh);
+                    const bf16x8 vr = ld16(&vi[la.row[0]]);
+                    dKh = mfma32(duh[0], vr, zero4());                                   // V dU
+                    dKh = mfma32(dul[0], vr, dKh);
+                }
+                {
+                    const bf16x8 drr = ld16(&drh[la.row[1]]);
+                    dZt = mfma32(s0h[1], drr, dZt);
+                    dZt = mfma32(s0l[1], drr, dZt);
+                    dZt = mfma32(s0h[1], ld16(&drl[la.row[1]]), dZt);
+                    const bf16x8 dyr = ld16(&dyi[la.row[1]]);
+                    dQt = mfma32(s0h[1], dyr, dQt);
+                    dQt = mfma32(s0l[1], dyr, dQt);
+                    const bf16x8 sah = ld16(&B.sa[0][la.row[1]]);
+                    dAh = mfma32(duh[1], sah, dAh);
+                    dAh = mfma32(dul[1], sah, dAh);
+                    dAh = mfma32(duh[1], ld16(&B.sa[1][la.row[1]]), dAh);
+                    const bf16x8 vr = ld16(&vi[la.row[1]]);
+                    dKh = mfma32(duh[1], vr, dKh);
+                    dKh = mfma32(dul[1], vr, dKh);
+                }
+                s0h_p[0] = s0h[0]; s0h_p[1] = s0h[1]; s0l_p[0] = s0l[0]; s0l_p[1] = s0l[1];
+                WKV_STAMP(6)
+            }
+            WKV_STAMP(0)
+            // ---------------------------------------------------------------- dM products
+            const bf16x8 qzh = mk8(lds_read_tr16(&B.opnd[2][la.trc]), lds_read_tr16(&B.opnd[0][la.trc]));      // [Qt^T | Zt^T]
+            const bf16x8 qzl = mk8(lds_read_tr16(&B.opnd[3][la.trc]), lds_read_tr16(&B.opnd[1][la.trc]));
+            const bf16x8 akh = mk8(lds_read_tr16(&B.opnd[4][la.trc]), lds_read_tr16(&B.opnd[6][la.trc]));      // [Ah^T | Kh^T]
+            const bf16x8 akl = mk8(lds_read_tr16(&B.opnd[5][la.trc]), lds_read_tr16(&B.opnd[7][la.trc]));
+            lds_flag_wait(&lds.flag[1], n_dm);
+            WKV_STAMP(1)
+            {
+                // dZt += dM_za Ah + dM_zk Kh ; dQt += dM_qa Ah + dM_qk Kh : X = [Ah^T | Kh^T], Y = pair image rows
+                {
+                    const bf16x8 zh = ld16(&lds.dsc[0][la.hl]), qh = ld16(&lds.dsc[2][la.hl]);
+                    dZt = mfma32(akh, zh, dZt);
+                    dZt = mfma32(akl, zh, dZt);
+                    dZt = mfma32(akh, ld16(&lds.dsc[1][la.hl]), dZt);
+                    dQt = mfma32(akh, qh, dQt);
+                    dQt = mfma32(akl, qh, dQt);
+                    dQt = mfma32(akh, ld16(&lds.dsc[3][la.hl]), dQt);
+                }
+                // dAh += dM_za^T Zt + dM_qa^T Qt ; dKh += dM_zk^T Zt + dM_qk^T Qt : X = [Qt^T | Zt^T], Y = [qX^T ; zX^T]
+                {
+                    const bf16x8 yh = mk8(lds_read_tr16(&lds.dsc[2][la.hlt]), lds_read_tr16(&lds.dsc[0][la.hlt]));
+                    dAh = mfma32(qzh, yh, dAh);
+                    dAh = mfma32(qzl, yh, dAh);
+                    dAh = mfma32(qzh, mk8(lds_read_tr16(&lds.dsc[3][la.hlt]), lds_read_tr16(&lds.dsc[1][la.hlt])), dAh);
+                }
+                {
+                    const bf16x8 yh = mk8(lds_read_tr16(&lds.dsc[2][la.hlt + 4]), lds_read_tr16(&lds.dsc[0][la.hlt + 4]));
+                    dKh = mfma32(qzh, yh, dKh);
+                    dKh = mfma32(qzl, yh, dKh);
+                    dKh = mfma32(qzh, mk8(lds_read_tr16(&lds.dsc[3][la.hlt + 4]), lds_read_tr16(&lds.dsc[1][la.hlt + 4])), dKh);
+                }
+            }
+            // results: lane = token c16, registers = channels 16w + 4g + e -> the fp32 image of the P waves' tail, once the tail of
+            // the chunk before (this step's, steps 3 ..) has read it: 4 P waves per tail
+            if (!(SKIP & 1) && n >= 3) lds_flag_wait(&lds.flag[4], 4u * (unsigned)(n - 2));
+            *reinterpret_cast<float4*>(&lds.res[0][la.f32]) = make_float4(dZt[0], dZt[1], dZt[2], dZt[3]);
+            *reinterpret_cast<float4*>(&lds.res[1][la.f32]) = make_float4(dQt[0], dQt[1], dQt[2], dQt[3]);
+            *reinterpret_cast<float4*>(&lds.res[2][la.f32]) = make_float4(dAh[0], dAh[1], dAh[2], dAh[3]);
+            *reinterpret_cast<float4*>(&lds.res[3][la.f32]) = make_float4(dKh[0], dKh[1], dKh[2], dKh[3]);
+        }
+        WKV_STAMP(2)
+        block_sync_lds();
+        WKV_STAMP(3)
+    }
+    WKV_STAMP_FLUSH(256, 5, 5)
+    if (PROF && blockIdx.x == 0 && tid == 256) { p.dbg[16] = tacc_[5]; p.dbg[17] = tacc_[6]; }   // j-split: operand reads + split | outputs
+}
+
+}  // namespace wkv7v8

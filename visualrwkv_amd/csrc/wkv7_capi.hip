@@ -8,6 +8,8 @@
 #include <wkv7_fwd_v3.h>
 #include <wkv7_bwd_v5.h>
 #include <wkv7_bwd_v6.h>
+#include <wkv7_bwd_v7.h>
+#include <wkv7_bwd_v8.h>
 
 namespace {
 
@@ -26,7 +28,7 @@ constexpr int BWD_V5_MODE = 2 + 4 + 128;
 constexpr long FWD_ISPLIT_MAX_HEADS = 128;
 // same-box A/B on MI355X, B=16 x 2624 x 32 heads: micro-benchmark (random inputs) 1.042 -> 0.993 ms, inside the training step
 // (bench.py, VRWKV_BWD_VARIANT=5 / 6) 0.981 -> 0.872 ms
-constexpr bool BWD_DEFAULT_V6 = true;
+constexpr int BWD_DEFAULT = 8;          // 5: wkv7_bwd_v5.h   6: wkv7_bwd_v6.h   7: wkv7_bwd_v7.h   8: wkv7_bwd_v8.h (one dS copy, T on P wave 0, full-row LDS-DMA)
 
 inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 
@@ -64,7 +66,7 @@ int vrwkv_wkv7_set_forward_variant(int variant) {
 }
 
 int vrwkv_wkv7_set_backward_variant(int variant) {
-    if (variant != -1 && variant != 5 && variant != 6 && !(variant >= 60 && variant < 68)) return VRWKV_EINVAL;   // see include/visualrwkv_hip.h
+    if (variant != -1 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && !(variant >= 60 && variant < 90)) return VRWKV_EINVAL;   // see include/visualrwkv_hip.h
     g_bwd_variant = variant;
     return VRWKV_OK;
 }
@@ -135,7 +137,48 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H, const void* w, const void* q, 
                     (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)((long)B * H));
-    if (g_bwd_variant == 6 || (g_bwd_variant >= 60 && g_bwd_variant < 68) || (g_bwd_variant == -1 && BWD_DEFAULT_V6)) {
+    int var = g_bwd_variant == -1 ? BWD_DEFAULT : g_bwd_variant;
+    const bool fits32 = (unsigned long long)B * T * H * 64ull * 4ull < (1ull << 32);      // wkv7_bwd_v8.h uses 32-bit byte offsets inside a tensor
+    if (!fits32 && (var == 8 || var >= 80)) var = 6;
+    if (var == 8 || (var >= 80 && var < 90)) {
+        // one copy of dL/dS, T chain on P wave 0, full-row memory role, 12 waves (wkv7_bwd_v8.h)
+        void (*kern)(wkv7::BwdArgs) = &wkv7v8::bwd_kernel_v8<false>;
+#ifdef VRWKV_V6_EXPERIMENTS   // role-timing builds: one or two roles switched off, results garbage
+        switch (g_bwd_variant) {
+            case 81: kern = &wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 1>; break;     // no P
+            case 82: kern = &wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 2>; break;     // no I
+            case 83: kern = &wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 4>; break;     // no J
+            case 84: kern = &wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 3>; break;     // J alone
+            case 85: kern = &wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 5>; break;     // I alone
+            case 86: kern = &wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 6>; break;     // P alone
+            case 87: kern = &wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 7>; break;     // barriers only
+            default: break;
+        }
+#endif
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)sizeof(wkv7v8::LdsV8));
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kern, grid, dim3(768), sizeof(wkv7v8::LdsV8), st, p);
+    } else if (var == 7 || (var >= 70 && var < 78)) {
+        // three-stage wave pipeline with a full-row memory role, 12 waves (wkv7_bwd_v7.h)
+        void (*kern)(wkv7::BwdArgs) = &wkv7v7::bwd_kernel_v7<false>;
+#ifdef VRWKV_V6_EXPERIMENTS   // role-timing builds: one or two roles switched off, results garbage
+        switch (g_bwd_variant) {
+            case 71: kern = &wkv7v7::bwd_kernel_v7<false, 0, 0, 1, 1>; break;     // no P
+            case 72: kern = &wkv7v7::bwd_kernel_v7<false, 0, 0, 1, 2>; break;     // no I
+            case 73: kern = &wkv7v7::bwd_kernel_v7<false, 0, 0, 1, 4>; break;     // no J
+            case 74: kern = &wkv7v7::bwd_kernel_v7<false, 0, 0, 1, 3>; break;     // J alone
+            case 75: kern = &wkv7v7::bwd_kernel_v7<false, 0, 0, 1, 5>; break;     // I alone
+            case 76: kern = &wkv7v7::bwd_kernel_v7<false, 0, 0, 1, 6>; break;     // P alone
+            case 77: kern = &wkv7v7::bwd_kernel_v7<false, 0, 0, 1, 7>; break;     // barriers only
+            default: break;
+        }
+#endif
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)sizeof(wkv7v7::LdsV7));
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kern, grid, dim3(768), sizeof(wkv7v7::LdsV7), st, p);
+    } else if (var == 6 || (var >= 60 && var < 68)) {
         // three-stage wave pipeline, 12 waves (wkv7_bwd_v6.h)
         void (*kern)(wkv7::BwdArgs) = &wkv7v6::bwd_kernel_v6<false>;
 #ifdef VRWKV_V6_EXPERIMENTS   // role-timing builds (VRWKV_EXTRA_HIPCC_FLAGS=-DVRWKV_V6_EXPERIMENTS): one or two roles switched off, results garbage
@@ -227,6 +270,22 @@ int vrwkv_wkv7_profile_bf16(int backward, int B, int T, int H, const void* w, co
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(kern, grid, dim3(768), sizeof(wkv7v6::LdsV6), st, p);
 #endif
+    } else if (backward == 4) {                     // wkv7_bwd_v8.h: same stamps as v6
+        wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
+                        (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
+                        (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da, dbg};
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7v8::bwd_kernel_v8<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7v8::LdsV8));
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((wkv7v8::bwd_kernel_v8<true>), grid, dim3(768), sizeof(wkv7v8::LdsV8), st, p);
+    } else if (backward == 3) {                     // three-stage pipeline with the full-row memory role (wkv7_bwd_v7.h): same stamps as v6
+        wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
+                        (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
+                        (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da, dbg};
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7v7::bwd_kernel_v7<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7v7::LdsV7));
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((wkv7v7::bwd_kernel_v7<true>), grid, dim3(768), sizeof(wkv7v7::LdsV7), st, p);
     } else if (backward == 2) {                     // three-stage pipeline (wkv7_bwd_v6.h): I / J / P wave 0, five stamps each
         wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                         (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
