@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void bwd_role(Args p) {
 // 512 threads: waves 4-7 load 6 arrays (narrow, one chunk ahead), waves 0-3 store y (bf16), sa (f32), s (16 KB per chunk).
 // ST: 1 = as shipped (2-byte y stores x4, 4-byte sa x4, 4-byte s x16)   2 = 8-byte y, 16-byte sa, 16-byte s x4 (quad-transposed)
 //     3 = full rows through LDS: s as 16 x 1 KB (4 per wave), sa 4 x 1 KB, y 2 x 1 KB
-template <int ST>
+template <int ST, int LD = 1>          // LD: 1 narrow register loads (as shipped) | 3 full rows by LDS-DMA (12 x 1 KB per chunk, 3 per producer wave)
 __global__ __launch_bounds__(512) void fwd_role(Args p) {
     char* lds = dyn_lds();
     uint32_t* img = reinterpret_cast<uint32_t*>(lds);
@@ -189,17 +189,38 @@ __global__ __launch_bounds__(512) void fwd_role(Args p) {
 #pragma unroll
             for (int a = 0; a < 6; ++a) r[a] = *reinterpret_cast<const u32x2_t*>(p.in[a] + u);
         };
-        fetch(0);
-        for (int c = 0; c < nchunk; ++c) {
+        uint32_t* stage = img + 8192;                                   // 2 x 12 KB from byte 32768
+        const unsigned wide_row = (unsigned)(lane >> 3), wide_oct = (unsigned)(lane & 7);
+        auto dma_fetch = [&](int c) {
 #pragma unroll
-            for (int a = 0; a < 6; ++a) { acc[0] ^= r[a][0]; acc[1] ^= r[a][1]; }
-            if (c + 1 < nchunk) fetch(c + 1);
+            for (int k = 0; k < 3; ++k) {
+                const int i = w + 4 * k;                                // array i >> 1, token half i & 1
+                lds_dma16(p.in[i >> 1] + head_base + (size_t)c * L * ts + (size_t)(8 * (i & 1) + wide_row) * ts + 8 * wide_oct, stage + (c & 1) * 3072 + i * 256);
+            }
+        };
+        if (LD == 1) fetch(0); else { dma_fetch(0); vmem_drain(); block_sync_lds(); }
+        for (int c = 0; c < nchunk; ++c) {
+            if (LD == 1) {
+#pragma unroll
+                for (int a = 0; a < 6; ++a) { acc[0] ^= r[a][0]; acc[1] ^= r[a][1]; }
+                if (c + 1 < nchunk) fetch(c + 1);
+            } else {
+                if (c + 1 < nchunk) dma_fetch(c + 1);
+                const uint32_t* st = stage + (c & 1) * 3072;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    const u32x2_t v = *reinterpret_cast<const u32x2_t*>(st + a * 512 + c16 * 32 + ((2 * w + (g >> 1)) ^ (c16 & 7)) * 4 + (g & 1) * 2);
+                    acc[0] ^= v[0]; acc[1] ^= v[1];
+                }
+                vmem_drain();
+            }
             img[4096 + tid] = acc[0] ^ acc[1];
             block_sync_lds();
         }
         return;
     }
     const int w = wave;
+    if (LD != 1) block_sync_lds();
     float* s_c0 = p.s_out + (size_t)bh * nchunk * N * N;
     for (int c = 0; c < nchunk; ++c) {
         const uint32_t seed = img[4096 + 256 + tid];
@@ -330,6 +351,7 @@ int main(int argc, char** argv) {
         fflush(stdout);
     }
 
+    const bool only_fwd = argc > 2;
     // ---- backward-like P role
     auto run_bwd = [&](const char* name, auto kern, size_t lds, double bytes_per_elem) {
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -338,6 +360,7 @@ int main(int argc, char** argv) {
         fflush(stdout);
     };
     const size_t L1 = 155 * 1024, L2 = 80 * 1024;
+    if (!only_fwd) {
     //                                                        LD ST S0 PF
     run_bwd("narrow loads + S0 dma + narrow stores (as shipped), 1 wg/cu", &bwd_role<1, 1, true, 1>, L1, 46);
     run_bwd("narrow loads + S0 dma + narrow stores, prefetch 2, 1 wg/cu", &bwd_role<1, 1, true, 2>, L1, 46);
@@ -356,6 +379,7 @@ int main(int argc, char** argv) {
     run_bwd("narrow loads + S0 dma + wide stores, 1 wg/cu", &bwd_role<1, 2, true, 1>, L1, 46);
     run_bwd("wide LDS-DMA loads + S0 dma, no stores, 1 wg/cu", &bwd_role<3, 0, true, 1>, L1, 34);
 
+    }
     // ---- forward-like roles (two workgroups per CU, as the kernel at B = 16)
     auto run_fwd = [&](const char* name, auto kern, size_t lds) {
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -366,6 +390,10 @@ int main(int argc, char** argv) {
     run_fwd("narrow loads + scalar stores (as shipped), 2 wg/cu", &fwd_role<1>, L2);
     run_fwd("narrow loads + 16-byte fragment stores, 2 wg/cu", &fwd_role<2>, L2);
     run_fwd("narrow loads + full-row stores through LDS, 2 wg/cu", &fwd_role<3>, L2);
+    run_fwd("full-row LDS-DMA loads + scalar stores, 2 wg/cu", &fwd_role<1, 3>, L2);
+    run_fwd("full-row LDS-DMA loads + 16-byte fragment stores, 2 wg/cu", &fwd_role<2, 3>, L2);
+    run_fwd("full-row LDS-DMA loads + full-row stores through LDS, 2 wg/cu", &fwd_role<3, 3>, L2);
+    run_fwd("full-row LDS-DMA loads + full-row stores through LDS, 1 wg/cu", &fwd_role<3, 3>, L1);
     run_fwd("narrow loads + scalar stores (as shipped), 1 wg/cu", &fwd_role<1>, L1);
     run_fwd("narrow loads + full-row stores through LDS, 1 wg/cu", &fwd_role<3>, L1);
     for (void* q : all) hipFree(q);

@@ -4,6 +4,7 @@
 #include <wkv7_kernels.h>
 #include <wkv7_chunked.h>
 #include <wkv7_fwd_v3.h>
+#include <wkv7_fwd_v4.h>
 #include <wkv7_bwd_v6.h>
 #include <wkv7_bwd_v7.h>
 #include <wkv7_bwd_v8.h>
@@ -18,6 +19,7 @@ int emu_wkv7_forward(int B, int T, int H, const void* w, const void* q, const vo
                     (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, s, sa};
     dim3 grid((unsigned)(B * H));
     if (variant == 6) emu::launch(dim3((unsigned)(2 * B * H)), dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1, 1, false, true, true, true>(p); });   // two workgroups per head
+    else if (variant == 7) emu::launch(grid, dim3(512), [&] { wkv7f4::fwd_kernel_v4<false>(p); });                                        // full-row memory traffic
     else if (variant == 1) emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1>(p); });                                // round-2 instantiation
     else if (variant == 2) emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1, 1, false, false, true>(p); });   // no Ab / Kb images
     else emu::launch(grid, dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1, 1, false, true, true>(p); });                      // default: + tr16 reads

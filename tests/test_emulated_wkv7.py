@@ -14,7 +14,7 @@ def P(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-@pytest.mark.parametrize("variant", [-1, 1, 2, 6])   # default (no Ab / Kb images, tr16 reads); 1: round-2 instantiation; 2: no Ab / Kb only; 6: two workgroups per head
+@pytest.mark.parametrize("variant", [-1, 1, 2, 6, 7])   # default (no Ab / Kb images, tr16 reads); 1: round-2 instantiation; 2: no Ab / Kb only; 6: two workgroups per head; 7: wkv7_fwd_v4.h (rows by LDS-DMA in, output images out)
 def test_forward_variants(emu_lib, variant):
     B, T, H, N = 2, 32, 2, 64
     w, q, k, v, z, a, _ = make_inputs(B, T, H, seed=variant + 1)
@@ -23,6 +23,19 @@ def test_forward_variants(emu_lib, variant):
     emu_lib.emu_wkv7_forward(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(y), P(s), P(sa), variant)
     assert rel_rms(y.float(), yr.float()) < 1e-3
     assert (y != yr).float().mean() < 0.01
+    assert rel_rms(s, sr) < 2e-5 and rel_rms(sa, sar) < 2e-5
+
+
+@pytest.mark.parametrize("T", [16, 48, 96])
+def test_forward_v4_chunk_counts(emu_lib, T):
+    """wkv7_fwd_v4.h with 1, 3 and 6 chunks: the V ring (3 slots), the single-buffered staging / output images and their
+    hand-off counters all wrap."""
+    B, H = 1, 2
+    w, q, k, v, z, a, _ = make_inputs(B, T, H, seed=100 + T)
+    yr, sr, sar = wkv7_c.forward(w, q, k, v, z, a)
+    y = torch.zeros_like(yr); s = torch.zeros_like(sr); sa = torch.zeros_like(sar)
+    emu_lib.emu_wkv7_forward(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(y), P(s), P(sa), 7)
+    assert rel_rms(y.float(), yr.float()) < 1e-3 and (y != yr).float().mean() < 0.01
     assert rel_rms(s, sr) < 2e-5 and rel_rms(sa, sar) < 2e-5
 
 

@@ -50,7 +50,7 @@ def _capi_backward(lib, w, q, k, v, z, a, dy, s, sa):
     return outs
 
 
-@pytest.mark.parametrize("variant", [-1, 1, 2])        # default (no Ab / Kb images + tr16 reads), round-2 instantiation, no Ab / Kb only
+@pytest.mark.parametrize("variant", [-1, 1, 2, 7])        # 7: wkv7_fwd_v4.h (full-row memory traffic); default (no Ab / Kb images + tr16 reads), round-2 instantiation, no Ab / Kb only
 @pytest.mark.parametrize("B,T,H", [(1, 16, 1), (2, 64, 3), (1, 384, 12), (3, 208, 5)])
 def test_forward_parity(hip_lib, dev, B, T, H, variant):
     w, q, k, v, z, a, _ = make_inputs(B, T, H, seed=B * 1000 + T + H)

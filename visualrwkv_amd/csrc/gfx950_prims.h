@@ -235,6 +235,9 @@ DEVFN void block_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" :
 // named barriers).  lds_flag_add: whole wave calls it after its LDS writes; lane 0 increments (the LDS unit executes a
 // wave's instructions in issue order, so the increment lands after the wave's writes).  lds_flag_wait: spin until
 // the counter reaches `target` (wrap-safe compare); the reads issued afterwards see the producers' writes.
+#ifndef VRWKV_FLAG_SLEEP
+#define VRWKV_FLAG_SLEEP 1          // units of 64 cycles between two polls of a waiting wave
+#endif
 DEVFN void lds_flag_add(unsigned* cnt) {
     const unsigned a = (unsigned)(uintptr_t)cnt;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -246,7 +249,7 @@ DEVFN void lds_flag_wait(unsigned* cnt, unsigned target) {
         unsigned v;
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
         if ((int)(__builtin_amdgcn_readfirstlane(v) - target) >= 0) break;
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(VRWKV_FLAG_SLEEP);
     }
 }
 // LDS ops of one wave execute in order; this only stops the compiler from moving LDS accesses

@@ -6,6 +6,7 @@
 #include <wkv7_kernels.h>
 #include <wkv7_chunked.h>
 #include <wkv7_fwd_v3.h>
+#include <wkv7_fwd_v4.h>
 #include <wkv7_bwd_v5.h>
 #include <wkv7_bwd_v6.h>
 #include <wkv7_bwd_v7.h>
@@ -26,6 +27,7 @@ constexpr int BWD_V5_MODE = 2 + 4 + 128;
 // few heads (B*H <= 128: at most half of the 256 CUs would be busy): two workgroups per head, 32 value rows each
 #define VRWKV_FWD_ISPLIT wkv7c::fwd_kernel_v3<false, false, 1, 1, false, true, true, true>
 constexpr long FWD_ISPLIT_MAX_HEADS = 128;
+constexpr bool FWD_DEFAULT_V4 = true;      // wkv7_fwd_v4.h (full-row memory traffic) for B*H > 128
 // same-box A/B on MI355X, B=16 x 2624 x 32 heads: micro-benchmark (random inputs) 1.042 -> 0.993 ms, inside the training step
 // (bench.py, VRWKV_BWD_VARIANT=5 / 6) 0.981 -> 0.872 ms
 constexpr int BWD_DEFAULT = 8;          // 5: wkv7_bwd_v5.h   6: wkv7_bwd_v6.h   7: wkv7_bwd_v7.h   8: wkv7_bwd_v8.h (one dS copy, T on P wave 0, full-row LDS-DMA)
@@ -60,7 +62,7 @@ const char* vrwkv_strerror(int code) {
 }
 
 int vrwkv_wkv7_set_forward_variant(int variant) {
-    if (variant != -1 && !(variant >= 1 && variant <= 5)) return VRWKV_EINVAL;   // 1..5: A/B instantiations of the same kernel
+    if (variant != -1 && !(variant >= 1 && variant <= 5) && variant != 7) return VRWKV_EINVAL;   // 1..5: A/B instantiations of wkv7_fwd_v3.h; 7: wkv7_fwd_v4.h
     g_fwd_variant = variant;
     return VRWKV_OK;
 }
@@ -93,6 +95,13 @@ int vrwkv_wkv7_forward_bf16(int B, int T, int H, const void* w, const void* q, c
         if (g_fwd_variant == 5) kern = &wkv7c::fwd_kernel_v3<false, false, 1, 2, false, false, true>;     // + two chunks of prefetch
         dim3 g2 = grid;
         if (g_fwd_variant == -1 && heads <= FWD_ISPLIT_MAX_HEADS) { kern = &VRWKV_FWD_ISPLIT; g2 = dim3((unsigned)(2 * heads)); }
+        if (g_fwd_variant == 7 || (g_fwd_variant == -1 && FWD_DEFAULT_V4 && heads > FWD_ISPLIT_MAX_HEADS)) {      // full-row memory traffic (wkv7_fwd_v4.h)
+            void (*k4)(wkv7::FwdArgs) = &wkv7f4::fwd_kernel_v4<false>;
+            hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7f4::LdsF4));
+            if (e4 != hipSuccess) return (int)e4;
+            hipLaunchKernelGGL(k4, grid, dim3(512), sizeof(wkv7f4::LdsF4), st, p);
+            return finish_launch();
+        }
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)sizeof(wkv7c::LdsF));
         if (e != hipSuccess) return (int)e;
@@ -243,7 +252,14 @@ int vrwkv_wkv7_profile_bf16(int backward, int B, int T, int H, const void* w, co
     if (!dbg) return VRWKV_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)((long)B * H));
-    if (!backward) {
+    if (!backward && (g_fwd_variant == 7 || (g_fwd_variant == -1 && FWD_DEFAULT_V4))) {
+        wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
+                        (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, s, sa, dbg};
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7f4::fwd_kernel_v4<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7f4::LdsF4));
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((wkv7f4::fwd_kernel_v4<true>), grid, dim3(512), sizeof(wkv7f4::LdsF4), st, p);
+    } else if (!backward) {
         wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                         (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, s, sa, dbg};
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&VRWKV_FWD_DEFAULT_PROF),
