@@ -400,12 +400,12 @@ def main():
             ms = sum(x for x, _ in kinds["bwd"]) / len(kinds["bwd"])
             elems = kinds["bwd"][0][1]
             ach = elems * BWD_B / ms / 1e6
-            out["roofline"] = {"bound": "hbm", "kernel": "wkv7v6::bwd_kernel_v6", "achieved": ach, "peak": HBM_PEAK_GBPS,
+            out["roofline"] = {"bound": "hbm", "kernel": {"5": "wkv7v5::bwd_kernel_v5", "6": "wkv7v6::bwd_kernel_v6", "7": "wkv7v7::bwd_kernel_v7"}.get(os.environ.get("VRWKV_BWD_VARIANT", ""), "wkv7v8::bwd_kernel_v8"), "achieved": ach, "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
                                "avg_ms": ms, "launches": len(kinds["bwd"]), "algorithmic_bytes": elems * BWD_B}
             if "fwd" in kinds:
                 msf = sum(x for x, _ in kinds["fwd"]) / len(kinds["fwd"])
-                out["roofline"]["fwd_kernel"] = {"kernel": "wkv7c::fwd_kernel_v3", "avg_ms": msf,
+                out["roofline"]["fwd_kernel"] = {"kernel": "wkv7c::fwd_kernel_v3" if os.environ.get("VRWKV_FWD_VARIANT", "-1") not in ("-1", "7") else "wkv7f4::fwd_kernel_v4", "avg_ms": msf,
                                                  "achieved": elems * FWD_B / msf / 1e6, "frac": elems * FWD_B / msf / 1e6 / HBM_PEAK_GBPS}
             copy = stream_copy_gbps(dev)                  # what a plain copy reaches on this box, random bytes
             out["roofline"]["stream_copy_GBps"] = copy

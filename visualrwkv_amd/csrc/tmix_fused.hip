@@ -330,53 +330,63 @@ struct KvaBwd {
                                                        // bonus term of `post`), summed here instead of by autograd
     const uint16_t* dvf_in;                            // optional: gradient of v_first collected by the layers after this one
 };
+// Two passes over the workgroup's token range -- the k / a-gate part, then the value-residual part: they share nothing but the
+// loop, and as one loop the kernel held 4 parameter vectors + 4 gradient accumulators + both parts' rows: 128 VGPRs and 88 B of
+// scratch per lane inside the token loop (3.5 TB/s where post_bwd reaches 5.4).  Per pass: 3 + 3 vectors (1 + 1 in the second).
 __global__ void kva_bwd_kernel(KvaBwd p) {
     const int c0 = threadIdx.x * 8, C = p.C;
-    const V8 kk_p = ld8f(p.k_k + c0), ka_p = ld8f(p.k_a + c0), a0 = ld8f(p.a0 + c0);
-    V8 v0 = zero8();
-    if (p.has_vres) v0 = ld8f(p.v0 + c0);
-    V8 g_kk = zero8(), g_ka = zero8(), g_a0 = zero8(), g_v0 = zero8();
-    for (long n = range_lo(p.ntok), hi = range_hi(p.ntok); n < hi; ++n) {
-        const long o = n * C + c0;
-        const V8 k = ld8f(p.k + o), al = ld8f(p.al + o);
-        V8 dk2 = ld8f(p.dk2 + o);
-        const V8 dz = ld8f(p.dz + o), db = ld8f(p.db + o);
-        if (p.dk2b) {
-            const V8 t = ld8f(p.dk2b + o);
+    const long lo = range_lo(p.ntok), hi = range_hi(p.ntok);
+    {
+        const V8 kk_p = ld8f(p.k_k + c0), ka_p = ld8f(p.k_a + c0), a0 = ld8f(p.a0 + c0);
+        V8 g_kk = zero8(), g_ka = zero8(), g_a0 = zero8();
+        for (long n = lo; n < hi; ++n) {
+            const long o = n * C + c0;
+            const V8 k = ld8f(p.k + o), al = ld8f(p.al + o);
+            V8 dk2 = ld8f(p.dk2 + o);
+            const V8 dz = ld8f(p.dz + o), db = ld8f(p.db + o);
+            if (p.dk2b) {
+                const V8 t = ld8f(p.dk2b + o);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) dk2.f[e] += t.f[e];
-        }
-        V8 a, u, kk, dkk, dk, dal;
-        float ss = 0.f;
+                for (int e = 0; e < 8; ++e) dk2.f[e] += t.f[e];
+            }
+            V8 a, u, kk, dkk, dk, dal;
+            float ss = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            a.f[e] = sigmoidf_(a0.f[e] + al.f[e]);
-            u.f[e] = k.f[e] * kk_p.f[e];
-            ss = fmaf(u.f[e], u.f[e], ss);
-        }
-        ss = group_sum<3>(ss);
-        const float nrm = fmaxf(sqrtf(ss), 1e-12f), inv = 1.f / nrm;
-        float dot = 0.f;
+            for (int e = 0; e < 8; ++e) {
+                a.f[e] = sigmoidf_(a0.f[e] + al.f[e]);
+                u.f[e] = k.f[e] * kk_p.f[e];
+                ss = fmaf(u.f[e], u.f[e], ss);
+            }
+            ss = group_sum<3>(ss);
+            const float nrm = fmaxf(sqrtf(ss), 1e-12f), inv = 1.f / nrm;
+            float dot = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            kk.f[e] = u.f[e] * inv;
-            dkk.f[e] = db.f[e] * a.f[e] - dz.f[e];              // z = -kk, b = kk*a
-            dot = fmaf(kk.f[e], dkk.f[e], dot);
-        }
-        dot = group_sum<3>(dot);
+            for (int e = 0; e < 8; ++e) {
+                kk.f[e] = u.f[e] * inv;
+                dkk.f[e] = db.f[e] * a.f[e] - dz.f[e];              // z = -kk, b = kk*a
+                dot = fmaf(kk.f[e], dkk.f[e], dot);
+            }
+            dot = group_sum<3>(dot);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float du = (dkk.f[e] - kk.f[e] * dot) * inv;  // d normalize
-            const float mod = 1.f + (a.f[e] - 1.f) * ka_p.f[e];
-            dk.f[e] = dk2.f[e] * mod + du * kk_p.f[e];
-            g_kk.f[e] = fmaf(du, k.f[e], g_kk.f[e]);
-            g_ka.f[e] = fmaf(dk2.f[e] * k.f[e], a.f[e] - 1.f, g_ka.f[e]);
-            const float da = db.f[e] * kk.f[e] + dk2.f[e] * k.f[e] * ka_p.f[e];
-            dal.f[e] = da * a.f[e] * (1.f - a.f[e]);
-            g_a0.f[e] += dal.f[e];
+            for (int e = 0; e < 8; ++e) {
+                const float du = (dkk.f[e] - kk.f[e] * dot) * inv;  // d normalize
+                const float mod = 1.f + (a.f[e] - 1.f) * ka_p.f[e];
+                dk.f[e] = dk2.f[e] * mod + du * kk_p.f[e];
+                g_kk.f[e] = fmaf(du, k.f[e], g_kk.f[e]);
+                g_ka.f[e] = fmaf(dk2.f[e] * k.f[e], a.f[e] - 1.f, g_ka.f[e]);
+                const float da = db.f[e] * kk.f[e] + dk2.f[e] * k.f[e] * ka_p.f[e];
+                dal.f[e] = da * a.f[e] * (1.f - a.f[e]);
+                g_a0.f[e] += dal.f[e];
+            }
+            st8f(p.dk + o, dk); st8f(p.dal + o, dal);
         }
-        st8f(p.dk + o, dk); st8f(p.dal + o, dal);
-        if (p.has_vres) {
+        put_partial(p.part, 4, 0, C, c0, g_kk); put_partial(p.part, 4, 1, C, c0, g_ka); put_partial(p.part, 4, 2, C, c0, g_a0);
+    }
+    V8 g_v0 = zero8();
+    if (p.has_vres) {
+        const V8 v0 = ld8f(p.v0 + c0);
+        for (long n = lo; n < hi; ++n) {
+            const long o = n * C + c0;
             const V8 v = ld8f(p.v + o), vf = ld8f(p.vfirst + o), vl = ld8f(p.vl + o);
             V8 dv2 = ld8f(p.dv2 + o);
             if (p.dv2b) {
@@ -401,8 +411,7 @@ __global__ void kva_bwd_kernel(KvaBwd p) {
             st8f(p.dv + o, dv); st8f(p.dvfirst + o, dvf); st8f(p.dvl + o, dvl);
         }
     }
-    put_partial(p.part, 4, 0, C, c0, g_kk); put_partial(p.part, 4, 1, C, c0, g_ka);
-    put_partial(p.part, 4, 2, C, c0, g_a0); put_partial(p.part, 4, 3, C, c0, g_v0);
+    put_partial(p.part, 4, 3, C, c0, g_v0);
 }
 
 // ---------------------------------------------------------------------------------------------- F4: GroupNorm + bonus + gate

@@ -23,6 +23,10 @@
 #include <wkv7_chunked.h>
 #include <wkv7_bwd_v7.h>     // ChunkImg7, RawP, DmaLane, dma_lane, prep7, dscores-style helpers; through it v6 / v5 building blocks
 
+#ifndef VRWKV_V8_ROTATE
+#define VRWKV_V8_ROTATE 1
+#endif
+
 namespace wkv7v8 {
 
 using wkv7::BwdArgs;
@@ -161,8 +165,12 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
         // One step.  FULL (steps 3 .. nchunk-2: a tail, a prep, a T, a non-empty S0 and a next chunk every time) has no
         // conditions: every path issues [6 row DMAs, 5-6 S0 DMAs (waves 1-3), 5 tail stores] in this order, so the wait before the
         // barrier is vmcnt(5): everything the other roles will read has landed, the stores stay in flight.
-        auto pstep = [&](int n, auto full_tag) {
+        // qt: the queue entry the tail consumes.  With SHIFT the three entries move up by one afterwards (q2 <- q1 <- q0 <- new);
+        // without, the new entry replaces the consumed one in place and the CALLER rotates the names (steady state, in threes:
+        // the 24 register moves of the shift are a twentieth of this role's instructions)
+        auto pstep = [&](int n, auto full_tag, TailRaw& qt, auto shift_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
+            constexpr bool SHIFT = decltype(shift_tag)::value;
             const int cp = nchunk - 1 - n, cd = cp + 1, ct = cp + 3;      // images | the I waves' chunk: T now, S0 for the J waves' next step | tail
             WKV_STAMP(4)
             if (!(SKIP & 1)) {
@@ -199,13 +207,14 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                         if (w == 1) s0_lean<0>(lds, sc, ll); else if (w == 2) s0_lean<1>(lds, sc, ll); else if (w == 3) s0_lean<2>(lds, sc, ll);
                     } else if (cd >= 0 && cd <= nchunk - 1) dma_state(lds.s0, cd > 0 ? sbase + (size_t)(cd - 1) * N * N : nullptr, k0, k1, lane);
                 }
-                if (FULL || (ct >= 0 && ct <= nchunk - 1)) tail7(lds, ct & 1, q2, p, head_base + (size_t)ct * L * ts, lane_boff, c16, w, g, la);
+                if (FULL || (ct >= 0 && ct <= nchunk - 1)) tail7(lds, ct & 1, qt, p, head_base + (size_t)ct * L * ts, lane_boff, c16, w, g, la);
                 WKV_STAMP(0)
-                q2 = q1; q1 = q0;
+                if (SHIFT) { q2 = q1; q1 = q0; }
+                TailRaw& qn = SHIFT ? q0 : qt;
                 if (do_prep) {
                     const Decay dd = prep7(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la);
-                    q0.q = raw.q; q0.k = raw.k; q0.z = raw.z; q0.a = raw.a;
-                    q0.x2[0] = dd.x2[0]; q0.x2[1] = dd.x2[1]; q0.x2[2] = dd.x2[2]; q0.x2[3] = dd.x2[3];
+                    qn.q = raw.q; qn.k = raw.k; qn.z = raw.z; qn.a = raw.a;
+                    qn.x2[0] = dd.x2[0]; qn.x2[1] = dd.x2[1]; qn.x2[2] = dd.x2[2]; qn.x2[3] = dd.x2[3];
                 }
                 WKV_STAMP(1)
                 if (FULL) vmem_wait<5>(); else vmem_drain();
@@ -215,9 +224,16 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
             WKV_STAMP(3)
         };
         int n = 0;
-        for (; n < 3 && n < nsteps; ++n) pstep(n, BoolTag<false>{});
-        for (; n < nchunk - 1; ++n) pstep(n, BoolTag<true>{});
-        for (; n < nsteps; ++n) pstep(n, BoolTag<false>{});
+        for (; n < 3 && n < nsteps; ++n) pstep(n, BoolTag<false>{}, q2, BoolTag<true>{});
+#if VRWKV_V8_ROTATE
+        for (; n + 2 < nchunk - 1; n += 3) {            // three steps: the entries rotate through the names and are back in place
+            pstep(n, BoolTag<true>{}, q2, BoolTag<false>{});
+            pstep(n + 1, BoolTag<true>{}, q1, BoolTag<false>{});
+            pstep(n + 2, BoolTag<true>{}, q0, BoolTag<false>{});
+        }
+#endif
+        for (; n < nchunk - 1; ++n) pstep(n, BoolTag<true>{}, q2, BoolTag<true>{});
+        for (; n < nsteps; ++n) pstep(n, BoolTag<false>{}, q2, BoolTag<true>{});
         WKV_STAMP_FLUSH(512, 10, 5)
         return;
     }
