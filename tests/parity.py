@@ -22,3 +22,22 @@ def bf16_close(x: torch.Tensor, ref: torch.Tensor, name: str = "", tol: float = 
     assert rms < tol, f"{name}: rel-RMS {rms:.3e} >= {tol:.1e} vs the bf16-rounded oracle (flips {flip:.4f})"
     assert flip < max_flip, f"{name}: {flip:.4f} of the elements differ from the bf16-rounded oracle (limit {max_flip})"
     return rms, flip
+
+
+def group_bias(x: torch.Tensor, ref: torch.Tensor, name: str = "", max_scale_err: float = 5e-3, min_cos_gap: float = None):
+    """A SYSTEMATIC error in one tensor -- a gradient group scaled by 1.01, a missing term -- hides inside a loose rel-RMS bound that
+    has to admit the random rounding noise of a bf16 pipeline (1e-2 .. 3e-2 against fp32).  The noise is unbiased, a systematic error
+    is not: the least-squares scale of x against ref, <x, ref> / <ref, ref>, is 1 up to noise / sqrt(n) for the former and off by
+    the error for the latter.  Returns (scale - 1, 1 - cosine)."""
+    xr = x.detach().double().cpu().reshape(-1)
+    rr = ref.detach().double().cpu().reshape(-1)
+    assert xr.shape == rr.shape, (name, xr.shape, rr.shape)
+    rr2 = float((rr * rr).sum())
+    scale = float((xr * rr).sum()) / max(rr2, 1e-300)
+    cos = float((xr * rr).sum()) / max(float(xr.norm() * rr.norm()), 1e-300)
+    if NOTES:
+        print(f"[parity] {name}: scale-1 {scale - 1:+.2e}  1-cos {1 - cos:.2e}")
+    assert abs(scale - 1) < max_scale_err, f"{name}: least-squares scale against the reference is {scale:.5f} (limit 1 +- {max_scale_err})"
+    if min_cos_gap is not None:
+        assert 1 - cos < min_cos_gap, f"{name}: 1 - cosine {1 - cos:.3e} >= {min_cos_gap}"
+    return scale - 1, 1 - cos

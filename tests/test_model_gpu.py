@@ -11,6 +11,7 @@ import pytest
 import torch
 
 from oracle.wkv7_oracle import rel_rms
+from tests.parity import group_bias
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "model_ref.pt")
@@ -156,17 +157,25 @@ def test_full_visual_step_matches_an_independent_fp32_cpu_evaluation(monkeypatch
     loss.backward()
     assert abs(float(loss) - float(loss_ref)) < 1e-2 * abs(float(loss_ref)), (float(loss), float(loss_ref))    # observed 11.3125 vs 11.3385
     named = dict(m.named_parameters())
-    checked, errs = 0, {}
+    checked, errs, bias = 0, {}, {}
+    # observed on MI355X (VRWKV_TEST_NOTES=1): scale - 1 = -0.4e-3 .. -2.7e-3, the same sign in every group: d(loss)/d(logits) is stored
+    # in bf16 as in the reference's bf16 pipeline, and its dominant entries -w (1 - p_label) have nearly the same value in every row
+    # of this batch (27-28 valid tokens per sample), so their rounding error (up to 2^-9) does not average out; a wrong term or factor
+    # in one group (1 % and more) still fails
+    SCALE_ERR = 8e-3
     for n, gr in gref.items():
         if gr.abs().max() == 0 or gr.numel() < 64:
             continue
         got = named[n].grad
         assert got is not None, n
         errs[n] = rel_rms(got.float().cpu(), gr)
+        if gr.numel() >= 1024:                 # unbiasedness of every larger gradient group: a systematic 1 % error would show here
+            bias[n] = group_bias(got.float(), gr, n, max_scale_err=SCALE_ERR)[0]
         checked += 1
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
     if os.environ.get("VRWKV_TEST_NOTES") == "1":
         print("[parity] e2e worst parameter-gradient groups:", [(n, round(e, 4)) for n, e in worst])
+        print("[parity] e2e largest |scale - 1| of a gradient group:", sorted(((abs(b), n) for n, b in bias.items()), reverse=True)[:5])
     assert all(e < 2.6e-2 for e in errs.values()), worst     # observed: worst 2.1e-2 (a token-shift mix parameter); bf16 path vs fp32
     assert checked >= 30
     # ---- one optimizer step on both sides (CPU: torch AdamW + clip_grad_norm_; GPU: ZeRO-1 engine, HIP AdamW with the clip

@@ -10,6 +10,7 @@ from oracle.wkv6_oracle import make_inputs6, wkv6_autograd
 import torch.nn as nn
 
 from oracle.wkv7_oracle import rel_rms
+from tests.parity import group_bias
 from tests.parity import bf16_close
 
 pytestmark = pytest.mark.gpu
@@ -169,6 +170,12 @@ def test_tmix_x060_against_reference_module(gold):
     named = dict(m.named_parameters())
     for k, gr in gold["tmix_grads_bf16"].items():
         assert rel_rms(named[k].grad.float().cpu(), gr.float()) < 3e-2, k
+    # unbiasedness (tests/parity.py::group_bias): a systematic error of 1 % in the output or in one gradient group fails here
+    group_bias(y.float(), gold["tmix_y_bf16"].float(), "x060 tmix y", max_scale_err=5e-3)
+    group_bias(x.grad.float(), gold["tmix_gx_bf16"].float(), "x060 tmix dx", max_scale_err=8e-3)
+    for k, gr in gold["tmix_grads_bf16"].items():
+        if gr.numel() >= 1024:
+            group_bias(named[k].grad.float(), gr.float(), "x060 tmix grad " + k, max_scale_err=1e-2)
 
 
 def _v6_args(fused):
@@ -205,6 +212,10 @@ def test_fused_x060_glue_matches_eager_modules():
         for n in g0:
             assert g1[n] is not None, n
             assert rel_rms(g1[n].float(), g0[n].float()) < 3e-2, (cls.__name__, n)
+            if g0[n].numel() >= 1024:
+                group_bias(g1[n].float(), g0[n].float(), f"{cls.__name__} fused vs eager grad {n}", max_scale_err=1e-2)
+        group_bias(y1.float(), y0.float(), f"{cls.__name__} fused vs eager y", max_scale_err=5e-3)
+        group_bias(gx1.float(), gx0.float(), f"{cls.__name__} fused vs eager dx", max_scale_err=8e-3)
 
 
 def test_ddmix_and_gn_silu_kernels_against_fp32():
