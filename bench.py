@@ -42,13 +42,13 @@ FWD_B, BWD_B = 34, 46          # algorithmic bytes per bf16 element at chunk len
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md
 
 
-def build_args(name, ctx_len, n_img_tokens, towers, grad_cp, fused, vit_minibatch=4):
+def build_args(name, ctx_len, n_img_tokens, towers, grad_cp, fused, vit_minibatch=4, image_size=None):
     m = MODELS[name]
     tiny = name == "tiny"
     return SimpleNamespace(n_layer=m["n_layer"], n_embd=m["n_embd"], dim_att=m["n_embd"], head_size_a=64,
                            head_size_divisor=8, vocab_size=65536, dropout=0, grad_cp=grad_cp, ctx_len=ctx_len,
                            load_model="", num_token_per_image=n_img_tokens, proj_type="mlp", vision_towers=towers,
-                           vision_image_size=56 if tiny else 448, vision_tower_kwargs=TINY_TOWERS if tiny else None,
+                           vision_image_size=image_size or (56 if tiny else 448), vision_tower_kwargs=TINY_TOWERS if tiny else None,
                            weight_decay=0.0, fused=fused, check_image_tokens=False, vit_minibatch=vit_minibatch)
 
 
@@ -220,6 +220,7 @@ def main():
     ap.add_argument("--ctx-len", type=int, default=2624)          # 576 image + 2048 text tokens
     ap.add_argument("--img-tokens", type=int, default=576)
     ap.add_argument("--towers", default="dino,siglip")
+    ap.add_argument("--image-size", type=int, default=0, help="side of the SigLIP / DINOv2 input (default 448; BASELINE config 1: 224 -> 256 patch tokens)")
     ap.add_argument("--grad-cp", type=int, default=0)
     ap.add_argument("--fused", type=int, default=1)
     ap.add_argument("--vit-minibatch", type=int, default=16, help="images per ViT forward (the reference's loop uses 4 to save memory)")
@@ -241,8 +242,8 @@ def main():
     ap.add_argument("--async-gather", type=int, default=1, help="overlap the parameter all-gather with the next ViT encode")
     a = ap.parse_args()
     cpu_mode = a.backend == "gloo"
-    if cpu_mode and a.model != "tiny":
-        ap.error("--backend gloo is the host-core plumbing mode: use --model tiny")
+    if cpu_mode and a.model not in ("tiny", "0b1"):
+        ap.error("--backend gloo is the host-core mode: --model tiny (plumbing) or --model 0b1 (BASELINE config 1: fp32, the op's CPU key)")
     if a.model == "tiny":          # shapes of the tiny plumbing model unless given explicitly
         given = {x.split("=")[0] for x in sys.argv[1:] if x.startswith("--")}
         if "--ctx-len" not in given: a.ctx_len = 64
@@ -294,7 +295,7 @@ def main():
     from visualrwkv_amd.dp import Zero1Engine
     from visualrwkv_amd.visual import VisualRWKV
     towers = tuple(t for t in a.towers.split(",") if t)
-    args = build_args(a.model, a.ctx_len, a.img_tokens, towers, a.grad_cp, bool(a.fused) and not cpu_mode, a.vit_minibatch)
+    args = build_args(a.model, a.ctx_len, a.img_tokens, towers, a.grad_cp, bool(a.fused) and not cpu_mode, a.vit_minibatch, a.image_size or None)
     dtype = torch.float32 if cpu_mode else torch.bfloat16     # host cores: BASELINE config 1's fp32 mode (the op's CPU key)
     torch.manual_seed(42)
     if a.fast_init:
@@ -310,7 +311,7 @@ def main():
     engine = Zero1Engine(model, lr=2e-5, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0, grad_clip=1.0, bucket_mb=200.0,
                          force_collectives=os.environ.get("VRWKV_FORCE_COLLECTIVES") == "1", async_gather=bool(a.async_gather))
     tiny = a.model == "tiny"
-    batch = synthetic_batch(a.micro_bsz, a.ctx_len, a.img_tokens, towers, dev, seed=1000 + rank, side=56 if tiny else 448,
+    batch = synthetic_batch(a.micro_bsz, a.ctx_len, a.img_tokens, towers, dev, seed=1000 + rank, side=a.image_size or (56 if tiny else 448),
                             sam_side=128 if tiny else 1024, dtype=dtype)
 
     data_kind = "synthetic"

@@ -45,3 +45,23 @@ def test_bench_starts_its_own_ranks_two_gloo_ranks_on_host_cores():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["ranks_seen_by_collective"] == 2 and rec["config"]["parallelism"] == "dp2"
     assert rec["config"]["global_batch"] == 4 and rec["value"] > 0 and 5.0 < rec["config"]["loss"] < 12.5
+
+
+def test_baseline_config_1_end_to_end_on_host_cores():
+    """BASELINE.json configs[0]: RWKV-x070 0.1B, fp32 CPU WKV path, one 224 x 224 dummy image (SigLIP-so400m/14: 256 patch tokens) +
+    128 text tokens, batch 1 -- one full training step (tower, projector, 12 blocks through the wind_backstepping op's CPU key, loss,
+    backward, ZeRO-1 AdamW) through the benchmark's own entry point.  Random-init weights: the first loss is ln 65536."""
+    import json
+    import math
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--backend", "gloo", "--model", "0b1", "--ctx-len", "384",
+                          "--img-tokens", "256", "--towers", "siglip", "--image-size", "224", "--micro-bsz", "1", "--steps", "1",
+                          "--warmup", "0", "--fast-init"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert line["dtype"] == "fp32" and line["config"]["seq_len"] == 384 and line["config"]["global_batch"] == 1
+    assert "256 img + 128 text" in line["config"]["workload"] and "siglip" in line["config"]["workload"]
+    assert abs(line["config"]["loss"] - math.log(65536)) < 0.5 and line["value"] > 0      # 11.09 +- the spread of a random head
