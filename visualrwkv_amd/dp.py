@@ -247,7 +247,12 @@ class Zero1Engine:
         if backend == "nccl":
             dist.reduce_scatter_tensor(piece, buf, op=dist.ReduceOp.SUM, group=self.pg)   # in place on own piece
         else:   # gloo has no reduce-scatter: all-reduce in the buffer's own dtype (bf16 sums in bf16, like RCCL), keep the own slice
-            dist.all_reduce(buf, group=self.pg)
+            try:
+                dist.all_reduce(buf, group=self.pg)
+            except RuntimeError:                 # a gloo build without bf16 reductions: sum in fp32, round once
+                wide = buf.float()
+                dist.all_reduce(wide, group=self.pg)
+                buf.copy_(wide)
 
     # ------------------------------------------------------------------ optimizer step
     @torch.no_grad()

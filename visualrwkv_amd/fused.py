@@ -691,9 +691,14 @@ ddmix = _DDMix.apply
 gn_silu = _GnSilu.apply
 
 
-def supported6(x):
-    """bf16 CUDA activations with C a multiple of 64 (the glue kernels' 8-channel lanes and 64-channel heads)."""
-    return x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 64 == 0 and x.shape[-1] <= 8192
+def supported6(x, m=None):
+    """bf16 CUDA activations with C a multiple of 64 (the glue kernels' 8-channel lanes and 64-channel heads).  With the time-mix
+    module `m`: its GroupNorm must be the 64-channel-per-head one over all C channels that gn_silu hard-codes (head_size 64,
+    dim_att == n_embd); anything else takes the eager path."""
+    ok = x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 64 == 0 and x.shape[-1] <= 8192
+    if ok and m is not None and hasattr(m, "ln_x"):
+        ok = getattr(m, "head_size", 64) == 64 and m.ln_x.num_groups * 64 == x.shape[-1] == m.ln_x.num_channels
+    return ok
 
 
 def tmix6_forward(m, x, wkv=None):

@@ -84,7 +84,7 @@ class RWKV_Tmix_x060(nn.Module):
         B, T, C = x.size()
         if getattr(self.args, "fused", False):
             from . import fused
-            if fused.supported6(x) and self.receptance.weight.dtype == torch.bfloat16:
+            if fused.supported6(x, self) and self.receptance.weight.dtype == torch.bfloat16:
                 return fused.tmix6_forward(self, x, wkv)
         r, k, v, g, w = self.mix(x)
         run = wkv if wkv is not None else _wkv6.RUN_CUDA_RWKV6
