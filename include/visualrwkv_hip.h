@@ -352,6 +352,14 @@ long vrwkv_wgrad_skinny_ws_floats(long M, int Nw, int D);
 int vrwkv_wgrad_skinny_bf16(long M, int Nw, int D, const void* wide, const void* narrow, void* out, int transposed,
                             float* ws, void* stream);
 
+/* ---- Weight gradient of a square / wide projection: out (N1 x N2, bf16) = A^T B for A (M x N1), B (M x N2) bf16 row-major, fp32
+ * accumulation (dW = dy^T x of nn.Linear: VisualRWKV-v7/v7.00/src/model.py:150-153 receptance / key / value / output, :214-215
+ * channel-mix key / value, :281 head; autograd's dy.t().mm(x)).  csrc/wgrad_big.h: both MFMA operands by transposing LDS reads from
+ * tiles stored as they lie in memory, split over M when the output has fewer tiles than the chip has CUs.  M % 32 == 0,
+ * N1 % 256 == 0, N2 % 256 == 0.  ws: vrwkv_wgrad_big_ws_floats(M,N1,N2) floats (0: none needed; -1: unsupported shape). */
+long vrwkv_wgrad_big_ws_floats(long M, int N1, int N2);
+int vrwkv_wgrad_big_bf16(long M, int N1, int N2, const void* A, const void* B, void* out, float* ws, void* stream);
+
 /* Streaming copy dst = src (bytes % 16 == 0): the on-box copy ceiling the WKV roofline fraction is also reported
  * against.  Moves 2 * bytes of HBM traffic. */
 int vrwkv_stream_copy(const void* src, void* dst, long bytes, void* stream);

@@ -100,3 +100,11 @@ extern "C" int emu_wkv7_forward_state_train(int B, int T, int H, const void* w, 
     emu::launch(dim3((unsigned)(B * H)), dim3(512), [&] { wkv7c::fwd_kernel_v3<false, false, 1, 1, false, true, true>(p); });
     return 0;
 }
+
+#include <wgrad_big.h>
+extern "C" int emu_wgrad_big(long M, int N1, int N2, int S, const void* A, const void* B, float* part, void* out) {
+    const wgb::Args a{M, N1, N2, S, (const uint16_t*)A, (const uint16_t*)B, part, (uint16_t*)out};
+    emu::launch(dim3((unsigned)((N1 / wgb::TM) * (N2 / wgb::TN) * S)), dim3(512), [&] { wgb::wgrad_big_kernel(a); });
+    if (S > 1) emu::launch(dim3(64), dim3(256), [&] { wgb::wgrad_big_reduce(part, S, (long)N1 * N2, (uint16_t*)out); });
+    return (int)(wgb::STAGES * 2 * wgb::OPB);
+}

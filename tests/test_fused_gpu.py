@@ -373,3 +373,22 @@ def test_ln_mix_is_the_two_kernel_path(B, T, C, M, has_delta, dup3):
             assert rel_rms(a.float().cpu(), b.float().cpu()) < 3e-3      # the kernel adds in fp32 and rounds once
     for a, b in zip(gp_f, gp_r):
         assert rel_rms(a.float().cpu(), b.float().cpu()) < 2e-3       # fp32 partial sums in another order, then one bf16 rounding
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 256, 256), (2048, 512, 256), (4128, 256, 768), (41984, 2048, 2048), (10496, 8192, 2048)])
+def test_big_weight_gradient_against_fp32(M, N, K):
+    """csrc/wgrad_big.h (dW = dy^T x of the Linear layers, VisualRWKV-v7/v7.00/src/model.py:150-153,214-215) against the fp32
+    product rounded once to bf16: one stage, ragged stage counts, the split-K shapes of the step (2048 x 2048 over 41 984 tokens:
+    4 slices) and a channel-mix shape; and through fused._LinearTN into a strided slot of a flat buffer."""
+    from tests.parity import bf16_close
+    from visualrwkv_amd import fused
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    dy = (torch.randn(M, N, device="cuda", generator=g) * 0.3).bfloat16()
+    x = (torch.randn(M, K, device="cuda", generator=g) * 0.5).bfloat16()
+    assert fused.wgrad_big_supported(dy, x)
+    ref = dy.float().t() @ x.float()
+    out = fused.wgrad_big(dy, x)
+    bf16_close(out, ref, f"wgrad_big {M}x{N}x{K}", tol=1e-3, max_flip=0.02)
+    flat = torch.zeros(N * K + 64, dtype=torch.bfloat16, device="cuda")
+    fused.wgrad_big(dy, x, out=flat[32:32 + N * K].view(N, K))
+    assert torch.equal(flat[32:32 + N * K].view(N, K), out) and float(flat[:32].abs().sum()) == 0 and float(flat[-32:].abs().sum()) == 0

@@ -3,6 +3,7 @@
 #include <stdint.h>
 #include "../../include/visualrwkv_hip.h"
 #include <lora_wgrad.h>
+#include <wgrad_big.h>
 
 namespace {
 
@@ -53,4 +54,44 @@ extern "C" int vrwkv_wgrad_skinny_bf16(long M, int Nw, int D, const void* wide, 
     hipLaunchKernelGGL(lwg::reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, ws, S, Nw, D, transposed, (uint16_t*)out);
     hipError_t e2 = hipGetLastError();
     return e2 == hipSuccess ? VRWKV_OK : (int)e2;
+}
+
+// ---- the square / wide weight gradients (wgrad_big.h): C (N1 x N2) = A^T B, A (M x N1), B (M x N2)
+namespace {
+// M-slices so that the grid has at least one workgroup per CU (256): the C x C shapes have 64 tiles -> 4 slices
+int big_splits(long M, int N1, int N2) {
+    const long tiles = (long)(N1 / wgb::TM) * (N2 / wgb::TN);
+    long s = (256 + tiles - 1) / tiles;
+    const long nst = M / wgb::KT;
+    if (s > 8) s = 8;
+    return (int)(s < 1 ? 1 : (s < nst ? s : nst));
+}
+}  // namespace
+
+extern "C" long vrwkv_wgrad_big_ws_floats(long M, int N1, int N2) {
+    if (M <= 0 || M % wgb::KT != 0 || N1 <= 0 || N2 <= 0 || N1 % wgb::TM != 0 || N2 % wgb::TN != 0) return -1;
+    const int S = big_splits(M, N1, N2);
+    return S > 1 ? (long)S * N1 * N2 : 0;
+}
+
+extern "C" int vrwkv_wgrad_big_bf16(long M, int N1, int N2, const void* A, const void* B, void* out, float* ws, void* stream) {
+    if (M <= 0 || !A || !B || !out) return VRWKV_EINVAL;
+    if (M % wgb::KT != 0 || N1 <= 0 || N2 <= 0 || N1 % wgb::TM != 0 || N2 % wgb::TN != 0) return VRWKV_ESHAPE;
+    if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(ws)) & 15u) return VRWKV_EALIGN;
+    const int S = big_splits(M, N1, N2);
+    if (S > 1 && !ws) return VRWKV_EINVAL;
+    const hipStream_t st = (hipStream_t)stream;
+    const wgb::Args a{M, N1, N2, S, (const uint16_t*)A, (const uint16_t*)B, ws, (uint16_t*)out};
+    const size_t lds = (size_t)wgb::STAGES * 2 * wgb::OPB;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgb::wgrad_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(wgb::wgrad_big_kernel, dim3((unsigned)((N1 / wgb::TM) * (N2 / wgb::TN) * S)), dim3(512), lds, st, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    if (S > 1) {
+        const long n = (long)N1 * N2;
+        hipLaunchKernelGGL(wgb::wgrad_big_reduce, dim3((unsigned)((n / 4 + 255) / 256 > 8192 ? 8192 : (n / 4 + 255) / 256)), dim3(256), 0, st, ws, S, n, (uint16_t*)out);
+        e = hipGetLastError();
+    }
+    return e == hipSuccess ? VRWKV_OK : (int)e;
 }

@@ -98,6 +98,31 @@ VF_CHAIN = os.environ.get("VRWKV_VF_CHAIN", "1") != "0"          # A/B switch: 0
 FLAT_WGRAD = os.environ.get("VRWKV_FLAT_WGRAD", "1") != "0"      # A/B switch: 0 = weight gradients as fresh tensors, copied into the ZeRO-1 buffer
 
 
+BIG_WGRAD = os.environ.get("VRWKV_BIG_WGRAD", "1") != "0"        # A/B switch: 0 = the library's "N,T" kernel for dW = dy^T x of the Linear layers
+
+
+def wgrad_big_supported(dy2d, x2d):
+    return (BIG_WGRAD and dy2d.is_cuda and dy2d.dtype == torch.bfloat16 and x2d.dtype == torch.bfloat16 and dy2d.is_contiguous()
+            and x2d.is_contiguous() and dy2d.shape[0] % 32 == 0 and dy2d.shape[1] % 256 == 0 and x2d.shape[1] % 256 == 0)
+
+
+def wgrad_big(dy2d, x2d, out=None):
+    """dy2d^T x2d for (M,N), (M,K) -> (N,K) bf16 (the weight gradient of nn.Linear, src/model.py:150-153,214-215,281) with
+    csrc/wgrad_big.h instead of the library's N,T-class kernel; `out`: a contiguous (N,K) bf16 view to write into."""
+    M, N = dy2d.shape
+    K = x2d.shape[1]
+    lib = hip_lib.load()
+    nws = lib.vrwkv_wgrad_big_ws_floats(M, N, K)
+    if nws < 0:
+        raise ValueError(f"wgrad_big: unsupported shape ({M},{N}) x ({M},{K})")
+    ws = torch.empty(nws, dtype=torch.float32, device=dy2d.device) if nws else None
+    if out is None:
+        out = torch.empty(N, K, dtype=torch.bfloat16, device=dy2d.device)
+    rc = lib.vrwkv_wgrad_big_bf16(M, N, K, dy2d.data_ptr(), x2d.data_ptr(), out.data_ptr(), ws.data_ptr() if ws is not None else 0, _stream(dy2d))
+    hip_lib.check(rc, "vrwkv_wgrad_big_bf16")
+    return out
+
+
 class _LinearTN(torch.autograd.Function):
     """F.linear(x, W) whose input gradient is issued in the layout of the forward GEMMs.  Autograd computes dx = dy.mm(W)
     with W (N_out, K_in) row-major: the contraction index is the strided one of W (hipBLASLt "N,N"), 8-15 % slower on
@@ -128,8 +153,13 @@ class _LinearTN(torch.autograd.Function):
                 # under one backward) must not write the slot again while autograd still holds the first gradient there.
                 flat, o = wp._vrwkv_flat_grad
                 dw = flat[o:o + wp.numel()].view(wp.shape)
-                torch.mm(dy2.t(), x2, out=dw)
+                if wgrad_big_supported(dy2, x2) and o % 8 == 0:
+                    wgrad_big(dy2, x2, out=dw)
+                else:
+                    torch.mm(dy2.t(), x2, out=dw)
                 wp._vrwkv_wgrad_pending = True
+            elif wgrad_big_supported(dy2, x2):
+                dw = wgrad_big(dy2, x2)
             else:
                 dw = dy2.t().mm(x2)
         return dx, dw

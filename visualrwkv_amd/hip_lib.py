@@ -78,6 +78,8 @@ PROTOTYPES = {
     "vrwkv_wkv7_profile_bf16": (_c_int, [_c_int] * 4 + [_c_void_p] * 18),
     "vrwkv_wgrad_skinny_ws_floats": (_c_long, [_c_long, _c_int, _c_int]),
     "vrwkv_wgrad_skinny_bf16": (_c_int, [_c_long, _c_int, _c_int] + [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 2),
+    "vrwkv_wgrad_big_ws_floats": (_c_long, [_c_long, _c_int, _c_int]),
+    "vrwkv_wgrad_big_bf16": (_c_int, [_c_long, _c_int, _c_int] + [_c_void_p] * 5),
     "vrwkv_stream_copy":(_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p]),
     "vrwkv_stream_probe": (_c_int, [_c_int] + [_c_void_p] * 4 + [_c_long, _c_void_p]),
     "vrwkv_transpose_bf16": (_c_int, [_c_long, _c_long, _c_void_p, _c_void_p, _c_void_p]),
