@@ -360,6 +360,7 @@ int vrwkv_wgrad_skinny_bf16(long M, int Nw, int D, const void* wide, const void*
 long vrwkv_wgrad_big_ws_floats(long M, int N1, int N2);
 int vrwkv_wgrad_big_bf16(long M, int N1, int N2, const void* A, const void* B, void* out, float* ws, void* stream);
 
+
 /* Streaming copy dst = src (bytes % 16 == 0): the on-box copy ceiling the WKV roofline fraction is also reported
  * against.  Moves 2 * bytes of HBM traffic. */
 int vrwkv_stream_copy(const void* src, void* dst, long bytes, void* stream);

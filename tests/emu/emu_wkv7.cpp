@@ -108,3 +108,4 @@ extern "C" int emu_wgrad_big(long M, int N1, int N2, int S, const void* A, const
     if (S > 1) emu::launch(dim3(64), dim3(256), [&] { wgb::wgrad_big_reduce(part, S, (long)N1 * N2, (uint16_t*)out); });
     return (int)(wgb::STAGES * 2 * wgb::OPB);
 }
+

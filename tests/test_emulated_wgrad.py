@@ -41,3 +41,4 @@ def test_big_weight_gradient_kernel(emu_lib, M, N1, N2, S):
     assert 0 < lds <= 160 * 1024
     ref = A.float().t() @ B.float()
     assert torch.equal(out.float(), ref.bfloat16().float()) or float((out.float() - ref).norm() / ref.norm()) < 2e-3
+

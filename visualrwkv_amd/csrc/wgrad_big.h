@@ -22,7 +22,10 @@
 namespace wgb {
 
 constexpr int TM = 256, TN = 256, KT = 32;          // tile of C, rows of M per stage
-constexpr int STAGES = 3;
+#ifndef WGB_STAGES
+#define WGB_STAGES 3
+#endif
+constexpr int STAGES = WGB_STAGES;
 constexpr int ROWB = TM * 2;                        // bytes of one LDS row (256 bf16)
 constexpr int OPB = KT * ROWB;                      // bytes of one operand tile of a stage (16 KB)
 
