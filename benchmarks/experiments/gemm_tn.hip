@@ -1,7 +1,7 @@
 // C-ABI of the T,N GEMM with an element-wise epilogue (gemm_tn.h).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "../../include/visualrwkv_hip.h"
+#include "../../include/visualrwkv_hip.h"      // error codes only: the entry point below is not declared there
 #include <gemm_tn.h>
 
 extern "C" int vrwkv_gemm_tn_bf16(long M, int N, int K, const void* A, const void* B, void* C, int epilogue, const void* aux, void* stream) {

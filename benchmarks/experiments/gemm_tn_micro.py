@@ -1,9 +1,11 @@
 """The channel-mix GEMMs with their epilogue inside (csrc/gemm_tn.h) against the library's T,N kernel + the streaming pass it replaces
 (M = 41 984 tokens, 2048 -> 8192): key projection + relu^2 (forward) and value's input gradient * 2 sqrt(h2) (backward)."""
 import json, os, sys, torch, torch.nn.functional as F
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 from visualrwkv_amd.gemm_tuning import enable_tuned_gemms
-from visualrwkv_amd import hip_lib, fused
+import ctypes
+from visualrwkv_amd import fused
 
 def bench(fn, iters=10):
     for _ in range(3): fn()
@@ -19,7 +21,9 @@ def bench(fn, iters=10):
 
 torch.cuda.set_device(0)
 n = enable_tuned_gemms() if "--no-tuned" not in sys.argv else 0
-lib = hip_lib.load(); st = torch.cuda.current_stream().cuda_stream
+lib = ctypes.CDLL(os.path.join(ROOT, "benchmarks", "_alt", "libgemm_tn.so"))          # built as benchmarks/experiments/README.md says
+lib.vrwkv_gemm_tn_bf16.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 2
+st = torch.cuda.current_stream().cuda_stream
 M, N, K = 41984, 8192, 2048
 x = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
 W = (torch.randn(N, K, device="cuda") * 0.02).bfloat16()
