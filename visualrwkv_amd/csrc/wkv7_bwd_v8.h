@@ -192,7 +192,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                 // dependent MFMA / split stages and nobody needs T before the I waves have formed dSA
                 if (w == 0 && (FULL || (cd >= 0 && cd <= nchunk - 1))) {
                     if (PT != PP) wave_priority<PT>();
-                    wkv7v6::scores6<TBF16, LdsV8, ChunkImg7, true>(lds, lds.b[cd % 3], 0, c16, g, la);
+                    if (!(SKIP & 8)) wkv7v6::scores6<TBF16, LdsV8, ChunkImg7, true>(lds, lds.b[cd % 3], 0, c16, g, la);      // SKIP bit 3 (timing experiment): no T chain
                     lds_flag_add(&lds.flag[2]);
                     if (PT != PP) wave_priority<PP>();
                 }

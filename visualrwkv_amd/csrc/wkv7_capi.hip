@@ -161,6 +161,7 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H, const void* w, const void* q, 
             case 85: kern = &wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 5>; break;     // I alone
             case 86: kern = &wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 6>; break;     // P alone
             case 87: kern = &wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 7>; break;     // barriers only
+            case 88: kern = &wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 8>; break;     // everything but the T chain (P wave 0 only raises its flag)
             default: break;
         }
 #endif
