@@ -47,7 +47,7 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     try:
         hl.load()
     except hl.HipLibraryError as e:
-        assert "no CPU or PyTorch fallback" in str(e)
+        assert "no PyTorch fallback" in str(e)
     else:
         raise AssertionError("expected HipLibraryError")
 

@@ -17,6 +17,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libvisualrwkv_hip.so")
+HOST_LIB_PATH = os.path.join(PKG_DIR, "libvisualrwkv_host.so")    # the op's CPU key alone: plain C++ (g++), no ROCm runtime needed to load it
 HASH_PATH = LIB_PATH + ".hash"      # content hash of the sources the library was built from; travels with it
 ARCH = "gfx950"
 
@@ -136,5 +137,30 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def build_host(force: bool = False) -> str:
+    """csrc/wkv7_host.hip -- plain C++ despite its suffix: the host-core implementation behind the `CPU` dispatch key of
+    torch.ops.wind_backstepping -- compiled with the host compiler into a small library of its own, so that BASELINE config 1
+    (fp32, no GPU) runs on a machine without ROCm.  (The same translation unit is also part of libvisualrwkv_hip.so: the C-ABI
+    header declares its two entry points.)"""
+    src = os.path.join(CSRC, "wkv7_host.hip")
+    hdr = os.path.join(REPO_DIR, "include", "visualrwkv_hip.h")
+    if not force and os.path.exists(HOST_LIB_PATH) and os.path.getmtime(HOST_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        return HOST_LIB_PATH
+    cxx = shutil.which("g++") or shutil.which("clang++") or shutil.which("c++")
+    if cxx is None:
+        raise RuntimeError("no host C++ compiler (g++ / clang++) found for libvisualrwkv_host.so")
+    with open(HOST_LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            tmp = f"{HOST_LIB_PATH}.tmp{os.getpid()}"
+            subprocess.run([cxx, "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-x", "c++", "-I", os.path.join(REPO_DIR, "include"),
+                            src, "-o", tmp], check=True)
+            os.replace(tmp, HOST_LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return HOST_LIB_PATH
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv))

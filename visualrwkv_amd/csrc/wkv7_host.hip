@@ -13,7 +13,11 @@
 #include <string.h>
 #include <math.h>
 
+#include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -35,18 +39,77 @@ inline float ld(const float* p) { return *p; }
 inline void st(uint16_t* p, float x) { *p = f2bf(x); }
 inline void st(float* p, float x) { *p = x; }
 
+// A persistent pool of host threads (created on first use, reused by every call: the op runs once per layer and direction) that
+// hands out task indices through one atomic counter.  Nothing throws across the C boundary: a pool that cannot be created runs the
+// tasks on the calling thread.
+class Pool {
+public:
+    static Pool& get() { static Pool p; return p; }
+    // run body(0 .. n_tasks-1) on up to n_threads threads (0: hardware_concurrency), the caller included
+    template <class F>
+    void run(int n_tasks, int n_threads, F&& body) {
+        if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+        if (n_threads > n_tasks) n_threads = n_tasks;
+        if (n_threads <= 1) { for (int i = 0; i < n_tasks; ++i) body(i); return; }
+        std::lock_guard<std::mutex> call(call_mu_);                 // one parallel region at a time
+        grow(n_threads - 1);
+        const int helpers = (int)std::min<size_t>(workers_.size(), (size_t)(n_threads - 1));
+        std::function<void(int)> fn = body;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn; n_tasks_ = n_tasks; next_.store(0); active_ = helpers; wanted_ = helpers; ++epoch_;
+        }
+        cv_.notify_all();
+        for (int i = next_.fetch_add(1); i < n_tasks; i = next_.fetch_add(1)) body(i);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return active_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    Pool() = default;
+    ~Pool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++epoch_; }
+        cv_.notify_all();
+        for (auto& t : workers_) if (t.joinable()) t.join();
+    }
+    void grow(int n) {
+        while ((int)workers_.size() < n) {
+            try {
+                const int id = (int)workers_.size();
+                workers_.emplace_back([this, id] { loop(id); });
+            } catch (...) { break; }                              // out of threads: run with what exists
+        }
+    }
+    void loop(int id) {
+        unsigned long seen = 0;
+        for (;;) {
+            std::function<void(int)>* fn;
+            int n;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return epoch_ != seen; });
+                seen = epoch_;
+                if (stop_) return;
+                if (id >= wanted_) continue;                      // more workers exist than this call asked for
+                fn = fn_; n = n_tasks_;
+            }
+            for (int i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) (*fn)(i);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--active_ == 0) done_.notify_one();
+        }
+    }
+    std::mutex call_mu_, mu_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> workers_;
+    std::function<void(int)>* fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_tasks_ = 0, active_ = 0, wanted_ = 0;
+    unsigned long epoch_ = 0;
+    bool stop_ = false;
+};
+
 template <class F>
-void for_each_head(int n_tasks, int n_threads, F&& body) {
-    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
-    if (n_threads > n_tasks) n_threads = n_tasks;
-    if (n_threads <= 1) { for (int i = 0; i < n_tasks; ++i) body(i); return; }
-    std::atomic<int> next{0};
-    std::vector<std::thread> pool;
-    pool.reserve(n_threads);
-    for (int t = 0; t < n_threads; ++t)
-        pool.emplace_back([&] { for (int i = next.fetch_add(1); i < n_tasks; i = next.fetch_add(1)) body(i); });
-    for (auto& th : pool) th.join();
-}
+void for_each_head(int n_tasks, int n_threads, F&& body) { Pool::get().run(n_tasks, n_threads, body); }
 
 // One token of the recurrence on S[i][j] (i = value row, j = key column), src/model.py's op contract:
 //   sa_i = sum_j z_j S_ij ;  S_ij <- S_ij w_j + sa_i a_j + v_i k_j ;  y_i = sum_j S_ij q_j

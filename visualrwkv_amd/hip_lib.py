@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes
 import os
 
-from .build import LIB_PATH
+from .build import HOST_LIB_PATH, LIB_PATH
 
 _c_int, _c_void_p, _c_long, _c_float = ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_float
 
@@ -103,7 +103,8 @@ def load() -> ctypes.CDLL:
     if not os.path.exists(path):
         raise HipLibraryError(
             f"{path} is missing. Build it with `python -m visualrwkv_amd.build` "
-            "(hipcc --offload-arch=gfx950); there is no CPU or PyTorch fallback for the WKV7 operator.")
+            "(hipcc --offload-arch=gfx950); the GPU operators have no PyTorch fallback (CPU tensors go through the op's CPU key: "
+            "libvisualrwkv_host.so, hip_lib.load_host()).")
     lib = ctypes.CDLL(path)
     for name, (res, args) in PROTOTYPES.items():
         try:
@@ -112,6 +113,33 @@ def load() -> ctypes.CDLL:
             raise HipLibraryError(f"{path} does not export {name}; rebuild it") from e
         fn.restype, fn.argtypes = res, args
     _lib = lib
+    return lib
+
+
+_host_lib = None
+
+
+def load_host() -> ctypes.CDLL:
+    """The host-core WKV7 operator alone (libvisualrwkv_host.so, plain C++: `python -m visualrwkv_amd.build` or
+    build.build_host()): what the `CPU` dispatch key of torch.ops.wind_backstepping calls.  Loading it needs no ROCm runtime.
+    Falls back to the same two entry points inside libvisualrwkv_hip.so when only that library exists."""
+    global _host_lib
+    if _host_lib is not None:
+        return _host_lib
+    path = os.environ.get("VRWKV_HOST_LIB", HOST_LIB_PATH)
+    if not os.path.exists(path):
+        try:
+            from .build import build_host
+            path = build_host()
+        except Exception:                                    # no host compiler here: the HIP library carries the same code
+            _host_lib = load()
+            return _host_lib
+    lib = ctypes.CDLL(path)
+    for name in ("vrwkv_wkv7_forward_host", "vrwkv_wkv7_backward_host"):
+        res, args = PROTOTYPES[name]
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _host_lib = lib
     return lib
 
 

@@ -137,23 +137,28 @@ def _host_dtype(w, tensors, names):
     return B, T, H, 0 if w.dtype == torch.bfloat16 else 1
 
 
+def _check_host(rc, what):
+    if rc != 0:                 # the host library has no strerror of its own: the codes are those of include/visualrwkv_hip.h
+        raise RuntimeError(f"{what} failed with code {rc} (VRWKV_E*: include/visualrwkv_hip.h)")
+
+
 def _forward_host(w, q, k, v, z, a, y, s, sa):
     """`CPU` dispatch key (the reference has none, cuda/wkv7_op.cpp:26): csrc/wkv7_host.hip on the host cores."""
     B, T, H, code = _host_dtype(w, (w, q, k, v, z, a, y), "wqkvzay")
     _check_state(s, sa, B, T, H, w.device)
-    rc = hip_lib.load().vrwkv_wkv7_forward_host(B, T, H, code, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(),
+    rc = hip_lib.load_host().vrwkv_wkv7_forward_host(B, T, H, code, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(),
                                                 z.data_ptr(), a.data_ptr(), y.data_ptr(), s.data_ptr(), sa.data_ptr(), HOST_THREADS)
-    hip_lib.check(rc, "vrwkv_wkv7_forward_host")
+    _check_host(rc, "vrwkv_wkv7_forward_host")
 
 
 def _backward_host(w, q, k, v, z, a, dy, s, sa, dw, dq, dk, dv, dz, da):
     names = ("w", "q", "k", "v", "z", "a", "dy", "dw", "dq", "dk", "dv", "dz", "da")
     B, T, H, code = _host_dtype(w, (w, q, k, v, z, a, dy, dw, dq, dk, dv, dz, da), names)
     _check_state(s, sa, B, T, H, w.device)
-    rc = hip_lib.load().vrwkv_wkv7_backward_host(B, T, H, code, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), z.data_ptr(),
+    rc = hip_lib.load_host().vrwkv_wkv7_backward_host(B, T, H, code, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), z.data_ptr(),
                                                  a.data_ptr(), dy.data_ptr(), s.data_ptr(), sa.data_ptr(), dw.data_ptr(), dq.data_ptr(),
                                                  dk.data_ptr(), dv.data_ptr(), dz.data_ptr(), da.data_ptr(), HOST_THREADS)
-    hip_lib.check(rc, "vrwkv_wkv7_backward_host")
+    _check_host(rc, "vrwkv_wkv7_backward_host")
 
 
 def _no_cpu(*args):
