@@ -234,3 +234,26 @@ def test_weight_gradients_written_into_the_flat_buffer(monkeypatch):
         else:
             assert torch.equal(g1, g0)
         assert n1 > n0 if passes == 1 else True          # Linear weights sit in the buffer before any copy
+
+
+def test_flat_buffer_alias_never_leaves_the_engine_step():
+    """a weight-gradient GEMM may write into the ZeRO-1 flat buffer only between the engine's zero_grad() and step().
+    torch.autograd.grad after a step (or on a model whose engine was closed) must get tensors of its own, not views of that buffer."""
+    from visualrwkv_amd.dp import Zero1Engine
+    from visualrwkv_amd.rwkv7 import RWKV
+    args = SimpleNamespace(n_embd=256, n_layer=1, dim_att=256, head_size_a=64, head_size_divisor=8, vocab_size=512, dropout=0,
+                           grad_cp=0, ctx_len=32, fused=True, weight_decay=0.0)
+    torch.manual_seed(0)
+    m = RWKV(args).bfloat16().cuda()
+    eng = Zero1Engine(m, lr=1e-3, weight_decay=0.0, grad_clip=1.0, bucket_mb=0.05)
+    ids = torch.randint(0, 512, (2, 32), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    lo, hi = eng.flat_grad.data_ptr(), eng.flat_grad.data_ptr() + eng.flat_grad.numel() * 2
+    w = m.blocks[0].ffn.key.weight
+    eng.zero_grad()
+    m(m.emb(ids)).float().square().mean().backward()
+    assert lo <= w.grad.data_ptr() < hi                      # armed: the gradient sits in the buffer
+    eng.step(1e-3)
+    (g,) = torch.autograd.grad(m(m.emb(ids)).float().square().mean(), [w])
+    assert not (lo <= g.data_ptr() < hi)                     # disarmed by step(): a tensor of the caller's own
+    eng.close()
+    assert not hasattr(w, "_vrwkv_flat_grad")

@@ -262,6 +262,8 @@ class Zero1Engine:
         device on every path (float() of it synchronises; the step itself does not)."""
         lr = self.lr if lr is None else lr
         self.step_count += 1
+        for p in self.params:                        # until the next zero_grad a backward gets fresh gradient tensors again (a caller of
+            p._vrwkv_flat_armed = False              # torch.autograd.grad must never be handed an alias of the flat buffer)
         self.wait_params()
         for b in self.buckets[self._next_launch:]:   # in index order: buckets whose hooks never all fired (unused parameters)
             self._flush(b)
@@ -332,6 +334,14 @@ class Zero1Engine:
         if ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)
 
+    def close(self):
+        """Detach the engine from its parameters: weight-gradient GEMMs stop writing into this engine's flat buffer (a model that
+        outlives its engine, or gets a new one, must not keep the old buffer alive through its parameters)."""
+        for p in self.params:
+            for attr in ("_vrwkv_flat_grad", "_vrwkv_flat_armed", "_vrwkv_wgrad_pending"):
+                if hasattr(p, attr):
+                    delattr(p, attr)
+
     def zero_grad(self, set_to_none: bool = True):
         """set_to_none (default): detach `.grad` so that the next backward hands its gradient tensors over instead
         of adding into the flat buffer (no memset, no per-parameter add kernels; one backward per step).
@@ -341,6 +351,7 @@ class Zero1Engine:
             for p in self.params:
                 p.grad = None
                 p._vrwkv_wgrad_pending = False
+                p._vrwkv_flat_armed = True          # this engine expects ONE backward into its flat buffer before the next step()
         else:
             self.flat_grad.zero_()
             for k, p in enumerate(self.params):

@@ -145,9 +145,10 @@ class _LinearTN(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
             wp = ctx.wparam
-            if (FLAT_WGRAD and wp is not None and wp.grad is None and not getattr(wp, "_vrwkv_wgrad_pending", False)
+            if (FLAT_WGRAD and wp is not None and wp.grad is None and getattr(wp, "_vrwkv_flat_armed", False)
+                    and not getattr(wp, "_vrwkv_wgrad_pending", False)
                     and wp._vrwkv_flat_grad[0].dtype == dy.dtype):
-                # ZeRO-1 engine (dp.Zero1Engine), first gradient of this weight in the step: the GEMM writes into the weight's
+                # ZeRO-1 engine (dp.Zero1Engine) armed by its zero_grad(), first gradient of this weight in the step: the GEMM writes into the weight's
                 # slot of the flat gradient buffer; autograd adopts the returned view as `.grad` and the engine finds it in place.
                 # `pending` until the engine's hook has seen it: a second use of the same weight in one graph (two forward passes
                 # under one backward) must not write the slot again while autograd still holds the first gradient there.
