@@ -155,3 +155,96 @@ def test_buckets_are_reduced_in_index_order_whatever_order_gradients_arrive():
         eng.step()
         orders.append(launched)
     assert all(o == list(range(len(o))) for o in orders) and len({len(o) for o in orders}) == 1
+
+
+# ---- N = 4 over gloo with the real model and the real hooks: one rank's batch has no image ----------------------------------
+# (src/dataset.py:214-226: a text-only record carries no image placeholder; on that rank the projector gets NO gradient, so its
+# autograd hooks never fire there while the three other ranks reduce the projector's bucket.)
+
+def _tiny_visual():
+    import bench
+    from visualrwkv_amd.visual import VisualRWKV
+    args = bench.build_args("tiny", 48, 16, ("siglip",), 0, False)
+    torch.manual_seed(7)
+    m = VisualRWKV(args)
+    with torch.no_grad():
+        for _, p in m.rwkv.named_parameters():
+            if p.dim() >= 2 and float(p.abs().max()) == 0.0:
+                p.normal_(0, 0.01)
+    m.freeze_emb()
+    return m
+
+
+def _rank_batch(rank):
+    import bench
+    b = bench.synthetic_batch(1, 48, 16, ("siglip",), torch.device("cpu"), seed=500 + rank, side=56, dtype=torch.float32)
+    if rank == 3:                                            # the text-only record: no placeholder run, no pixels
+        g = torch.Generator().manual_seed(77)
+        b["input_ids"][:, 4:20] = torch.randint(0, 65535, (1, 16), generator=g)
+        del b["images"]
+    return b
+
+
+# eps = 1: the update is (nearly) linear in the gradient, so that the comparison below is one of gradients -- with the usual 1e-8 a
+# gradient that is zero up to rounding (LayerNorm biases in front of a shift-invariant op) becomes a full +-lr step of either sign
+_ENG4 = dict(lr=0.5, betas=(0.9, 0.99), eps=1.0, weight_decay=0.0, grad_clip=1.0, bucket_mb=0.05)
+
+
+def _worker4(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from visualrwkv_amd.dp import Zero1Engine
+    m = _tiny_visual()
+    eng = Zero1Engine(m, **_ENG4)
+    batch = _rank_batch(rank)
+    init = {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}
+    fired = []
+    for _ in range(2):
+        eng.zero_grad()
+        m.training_step(batch).backward()
+        fired.append(sorted(n for n, p in m.named_parameters() if n.startswith("proj.") and p.grad is not None and float(p.grad.abs().sum()) > 0))
+        eng.step()
+    torch.save({"params": {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}, "init": init, "proj_grads_step0": fired[0],
+                "n_buckets": len(eng.buckets)}, os.path.join(out_dir, f"r{rank}.pt"))
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_world4_gloo_with_a_rank_without_image(tmp_path):
+    from visualrwkv_amd.dp import Zero1Engine
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_worker4, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    rs = [torch.load(tmp_path / f"r{r}.pt") for r in range(4)]
+    assert rs[0]["n_buckets"] > 2                             # several buckets: the projector's is not the only one
+    assert len(rs[0]["proj_grads_step0"]) > 0 and rs[3]["proj_grads_step0"] == []     # rank 3 produced no projector gradient
+    for r in range(1, 4):
+        for n, a in rs[0]["params"].items():
+            assert torch.equal(a, rs[r]["params"][n]), n     # replicas stay identical
+    # one process: per-record backward (L2Wrap's penalty gradient does not scale with the loss weight, src/model.py:38-46, so the
+    # mean is taken over gradients, as data parallelism does), global-norm clip, torch's AdamW
+    m = _tiny_visual()
+    train = [p for p in m.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(train, lr=_ENG4["lr"], betas=_ENG4["betas"], eps=_ENG4["eps"], weight_decay=0.0)
+    for _ in range(2):
+        acc = [torch.zeros_like(p) for p in train]
+        for r in range(4):
+            gs = torch.autograd.grad(m.training_step(_rank_batch(r)), train, allow_unused=True)
+            for a, g in zip(acc, gs):
+                if g is not None:
+                    a.add_(g, alpha=0.25)
+        gn = float(torch.sqrt(sum((a.double() ** 2).sum() for a in acc)))
+        c = min(1.0, _ENG4["grad_clip"] / (gn + 1e-6))
+        for p, a in zip(train, acc):
+            p.grad = a * c
+        opt.step()
+    moved = 0
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            d_dp, d_one = rs[0]["params"][n] - rs[0]["init"][n], p.detach() - rs[0]["init"][n]
+            scale = float(d_one.abs().max())
+            assert float((d_dp - d_one).abs().max()) <= 1e-3 * scale + 1e-7, (n, scale, float((d_dp - d_one).abs().max()))
+            moved += int(n.startswith("proj.") and scale > 0)
+    assert moved > 0

@@ -265,14 +265,20 @@ class Zero1Engine:
         for p in self.params:                        # until the next zero_grad a backward gets fresh gradient tensors again (a caller of
             p._vrwkv_flat_armed = False              # torch.autograd.grad must never be handed an alias of the flat buffer)
         self.wait_params()
-        for b in self.buckets[self._next_launch:]:   # in index order: buckets whose hooks never all fired (unused parameters)
+        # Buckets whose hooks never all fired (unused parameters), in index order.  The slots of the unused parameters are zeroed
+        # FIRST, all of them: a parameter may span two buckets, and zeroing its whole view while launching the second would wipe
+        # the part the first bucket's reduction has already written.
+        if self._gather:
+            for b in self.buckets[self._next_launch:]:
+                if b.pending > 0:
+                    for k in b.param_ids:
+                        if not self._fired[k]:
+                            v = self._view(k)
+                            v.zero_()
+                            self.params[k].grad = v
+                            self._fired[k] = True
+        for b in self.buckets[self._next_launch:]:
             self._flush(b)
-            if b.pending > 0 and self._gather:
-                for k in b.param_ids:
-                    if not self._fired[k]:
-                        v = self._view(k)
-                        v.zero_()
-                        self.params[k].grad = v
             self._launch_reduce(b)
             b.launched = True
         self._next_launch = len(self.buckets)
