@@ -25,27 +25,32 @@ __global__ __launch_bounds__(256) void adamw_kernel(long n, float* __restrict__ 
         const float gnorm = sqrtf(*sqnorm) * grad_scale;
         if (clip > 0.f) grad_scale *= fminf(1.f, clip / (gnorm + 1e-6f));
     }
-    const long nvec = n >> 2;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
-        float4 p4 = reinterpret_cast<float4*>(master)[i];
-        float4 m4 = reinterpret_cast<float4*>(m)[i];
-        float4 v4 = reinterpret_cast<float4*>(v)[i];
-        const uint2 g2 = reinterpret_cast<const uint2*>(grad)[i];
-        float p[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
-        const float g[4] = {bf16_lo(g2.x) * grad_scale, bf16_hi(g2.x) * grad_scale, bf16_lo(g2.y) * grad_scale, bf16_hi(g2.y) * grad_scale};
+    // one 4-element vector per thread, no loop, non-temporal accesses (nothing here is read again before ~20 GB of other traffic):
+    // the grid-stride loop over 2048 workgroups ran at 5.4 TB/s; see relusq_fwd_kernel (tmix_fused.hip) for the measurement
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (n >> 2)) return;
+    typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2_nt __attribute__((ext_vector_type(2)));
+    const f32x4_nt p4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(master) + i);
+    const f32x4_nt m4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(m) + i);
+    const f32x4_nt v4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(v) + i);
+    const u32x2_nt g2 = __builtin_nontemporal_load(reinterpret_cast<const u32x2_nt*>(grad) + i);
+    float p[4] = {p4[0], p4[1], p4[2], p4[3]}, mm[4] = {m4[0], m4[1], m4[2], m4[3]}, vv[4] = {v4[0], v4[1], v4[2], v4[3]};
+    const float g[4] = {bf16_lo(g2[0]) * grad_scale, bf16_hi(g2[0]) * grad_scale, bf16_lo(g2[1]) * grad_scale, bf16_hi(g2[1]) * grad_scale};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float decay = (global_offset + 4 * i + e) < wd_boundary ? wd : 0.f;
-            mm[e] = b1 * mm[e] + (1.f - b1) * g[e];
-            vv[e] = b2 * vv[e] + (1.f - b2) * g[e] * g[e];
-            const float upd = (mm[e] * inv_bc1) / (sqrtf(vv[e]) * inv_sqrt_bc2 + eps) + decay * p[e];
-            p[e] -= lr * upd;
-        }
-        reinterpret_cast<float4*>(master)[i] = make_float4(p[0], p[1], p[2], p[3]);
-        reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
-        reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
-        reinterpret_cast<uint2*>(param)[i] = make_uint2(cvt_pk_bf16(p[0], p[1]), cvt_pk_bf16(p[2], p[3]));
+    for (int e = 0; e < 4; ++e) {
+        const float decay = (global_offset + 4 * i + e) < wd_boundary ? wd : 0.f;
+        mm[e] = b1 * mm[e] + (1.f - b1) * g[e];
+        vv[e] = b2 * vv[e] + (1.f - b2) * g[e] * g[e];
+        const float upd = (mm[e] * inv_bc1) / (sqrtf(vv[e]) * inv_sqrt_bc2 + eps) + decay * p[e];
+        p[e] -= lr * upd;
     }
+    const f32x4_nt po = {p[0], p[1], p[2], p[3]}, mo = {mm[0], mm[1], mm[2], mm[3]}, vo = {vv[0], vv[1], vv[2], vv[3]};
+    const u32x2_nt bo = {cvt_pk_bf16(p[0], p[1]), cvt_pk_bf16(p[2], p[3])};
+    __builtin_nontemporal_store(po, reinterpret_cast<f32x4_nt*>(master) + i);
+    __builtin_nontemporal_store(mo, reinterpret_cast<f32x4_nt*>(m) + i);
+    __builtin_nontemporal_store(vo, reinterpret_cast<f32x4_nt*>(v) + i);
+    __builtin_nontemporal_store(bo, reinterpret_cast<u32x2_nt*>(param) + i);
 }
 
 // out[0] += sum x^2 over a bf16 buffer (n % 8 == 0); one atomic per workgroup
@@ -80,7 +85,7 @@ int vrwkv_adamw_step_bf16(long n, float* master, float* m, float* v, const void*
     if (n <= 0 || !master || !m || !v || !grad || !param || step < 1) return VRWKV_EINVAL;
     if (n % 4 != 0) return VRWKV_ESHAPE;
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, (hipStream_t)stream, n, master, m, v,
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(((n >> 2) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, master, m, v,
                        (const uint16_t*)grad, (uint16_t*)param, lr, beta1, beta2, eps, weight_decay,
                        (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale, global_offset, wd_boundary, (const float*)nullptr, 0.f);
     hipError_t e = hipGetLastError();
@@ -94,7 +99,7 @@ int vrwkv_adamw_step_clip_bf16(long n, float* master, float* m, float* v, const 
     if (n <= 0 || !master || !m || !v || !grad || !param || !sqnorm || step < 1) return VRWKV_EINVAL;
     if (n % 4 != 0) return VRWKV_ESHAPE;
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, (hipStream_t)stream, n, master, m, v,
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(((n >> 2) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, master, m, v,
                        (const uint16_t*)grad, (uint16_t*)param, lr, beta1, beta2, eps, weight_decay,
                        (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), inv_world, global_offset, wd_boundary, sqnorm, clip);
     hipError_t e = hipGetLastError();

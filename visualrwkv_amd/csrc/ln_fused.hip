@@ -24,12 +24,24 @@ namespace {
 
 using namespace vln;
 
-constexpr int LN_GRID = 2048;
-inline int ln_grid(long ntok) { return (int)(ntok < LN_GRID ? ntok : LN_GRID); }
+#ifndef VRWKV_LN_BWD_GRID
+#define VRWKV_LN_BWD_GRID 1024
+#endif
+#ifndef VRWKV_LN_MIX_BWD_GRID
+#define VRWKV_LN_MIX_BWD_GRID 768
+#endif
+// Forward kernels: MANY short-lived workgroups keep more requests in flight than 2048 resident ones that walk 20 rows each
+// (profiles/r4_eltwise_micro_ab.jsonl): add + LayerNorm one row per workgroup (-20 %), the lerp kernels four (the shifted row
+// x[n-1] is the previous iteration's row in registers: with one row per workgroup it would be read and normalised twice)
+constexpr int LN_ROWS_PER_WG = 1, LN_MIX_ROWS_PER_WG = 4;
+inline int ln_grid(long ntok, int rows = LN_ROWS_PER_WG) {
+    const long g = (ntok + rows - 1) / rows;
+    return (int)(g < 1 ? 1 : g > (1L << 22) ? (1L << 22) : g);
+}
 // Backward kernels: one workgroup per resident slot (add_ln_bwd: 104 VGPRs, 4 workgroups of 256 threads per CU; ln_mix_bwd<1>: 162, 3 per
 // CU) -- a single round of equal token ranges, and half / a third of the partial rows for ln_colsum_kernel to read (2048 rows cost
 // 46 us per call, 2.3 ms per step)
-constexpr int LN_BWD_GRID = 1024, LN_MIX_BWD_GRID = 768;
+constexpr int LN_BWD_GRID = VRWKV_LN_BWD_GRID, LN_MIX_BWD_GRID = VRWKV_LN_MIX_BWD_GRID;
 inline int ln_bwd_grid(long ntok) { return (int)(ntok < LN_BWD_GRID ? ntok : LN_BWD_GRID); }
 inline int ln_mix_bwd_grid(long ntok) { return (int)(ntok < LN_MIX_BWD_GRID ? ntok : LN_MIX_BWD_GRID); }
 inline int ln_ok(int C) { return C > 0 && C % 64 == 0 && C <= 8192; }
@@ -118,7 +130,7 @@ int vrwkv_ln_mix_fwd_bf16(long ntok, int T, int C, float eps, int M, const void*
         if (!mu[j] || !out[j]) return VRWKV_EINVAL;
         pm.p[j] = (const uint16_t*)mu[j]; po.p[j] = (uint16_t*)out[j];
     }
-    const dim3 grid(ln_grid(ntok)), block(ln_threads(C));
+    const dim3 grid(ln_grid(ntok, LN_MIX_ROWS_PER_WG)), block(ln_threads(C));
     hipStream_t st = (hipStream_t)stream;
     if (M == 1) hipLaunchKernelGGL(ln_mix_fwd_kernel<1>, grid, block, 0, st, ntok, T, C, eps, (const uint16_t*)x, (const uint16_t*)delta,
                                    (const uint16_t*)w, (const uint16_t*)b, (uint16_t*)xn, mean, rstd, pm, po);

@@ -16,7 +16,28 @@ DEVFN V8 unpack8(uint4 u) {
 DEVFN uint4 pack8(const V8& v) {
     return make_uint4(cvt_pk_bf16(v.f[0], v.f[1]), cvt_pk_bf16(v.f[2], v.f[3]), cvt_pk_bf16(v.f[4], v.f[5]), cvt_pk_bf16(v.f[6], v.f[7]));
 }
-DEVFN uint4 ldg(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+// Row pieces are streamed: every activation row is read once and written once per kernel, and the tensors (172 MB and more) do not
+// survive in L2 / MALL until their consumer runs -- non-temporal accesses (measured per kernel in profiles/r4_eltwise_micro_ab.jsonl)
+#ifndef VRWKV_NT
+#define VRWKV_NT 1
+#endif
+typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
+DEVFN uint4 ldg(const uint16_t* p) {
+#if VRWKV_NT
+    const u32x4_nt u = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(p));
+    return make_uint4(u[0], u[1], u[2], u[3]);
+#else
+    return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+DEVFN void stg(uint16_t* p, uint4 v) {
+#if VRWKV_NT
+    const u32x4_nt u = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(u, reinterpret_cast<u32x4_nt*>(p));
+#else
+    *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
 // empty asm that "redefines" a packed loop-invariant row: keeps the compiler from hoisting its unpacked form (twice the registers)
 // out of the token loop
 DEVFN void keep_packed(uint4& u) { pin_vgpr4(u.x, u.y, u.z, u.w); }
@@ -74,7 +95,7 @@ __global__ __launch_bounds__(1024) void add_ln_fwd_kernel(long ntok, int C, floa
                 for (int e = 0; e < 8; ++e) v.f[e] += d.f[e];
             }
             const uint4 r = pack8(v);
-            if (act) *reinterpret_cast<uint4*>(xn + n * C + c0) = r;
+            if (act) stg(xn + n * C + c0, r);
             v = unpack8(r);
         }
         const int par = (int)(n & 1) * 2;
@@ -92,7 +113,7 @@ __global__ __launch_bounds__(1024) void add_ln_fwd_kernel(long ntok, int C, floa
 #pragma unroll
         for (int e = 0; e < 8; ++e) o.f[e] = fmaf((v.f[e] - mu) * rs, wv.f[e], bv.f[e]);
         const long orow = yrow ? yrow[n] : n;                  // yrow: scatter into a larger tensor; a negative row is dropped
-        if (act && orow >= 0) *reinterpret_cast<uint4*>(y + orow * C + c0) = pack8(o);
+        if (act && orow >= 0) stg(y + orow * C + c0, pack8(o));
         if (threadIdx.x == 0 && mean) { mean[n] = mu; rstd[n] = rs; }
     }
 }
@@ -143,7 +164,7 @@ __global__ __launch_bounds__(1024) void add_ln_bwd_kernel(long ntok, int C, cons
         V8 o = unpack8(cr);                         // zeros when there is no residual gradient
 #pragma unroll
         for (int e = 0; e < 8; ++e) o.f[e] = fmaf(rs, g.f[e] - c1 - xh.f[e] * c2, o.f[e]);
-        if (act) *reinterpret_cast<uint4*>(dx + n * C + c0) = pack8(o);
+        if (act) stg(dx + n * C + c0, pack8(o));
     }
     if (act) {
         float* dst = part + (size_t)blockIdx.x * 2 * C + c0;
@@ -235,7 +256,7 @@ __global__ __launch_bounds__(1024) void ln_mix_fwd_kernel(long ntok, int T, int 
 #pragma unroll
             for (int e = 0; e < 8; ++e) v.f[e] += d.f[e];
             const uint4 r = pack8(v);
-            if (act && own) *reinterpret_cast<uint4*>(xn + n * C + c0) = r;
+            if (act && own) stg(xn + n * C + c0, r);
             v = unpack8(r);
         }
         const int par = (int)(n & 1) * 2;
@@ -264,7 +285,7 @@ __global__ __launch_bounds__(1024) void ln_mix_fwd_kernel(long ntok, int T, int 
                 V8 r;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) r.f[e] = fmaf(xx.f[e], m.f[e], cur.f[e]);
-                if (act) *reinterpret_cast<uint4*>(out.p[j] + n * C + c0) = pack8(r);
+                if (act) stg(out.p[j] + n * C + c0, pack8(r));
             }
             if (threadIdx.x == 0) { mean[n] = mu_; rstd[n] = rs; }
         }
@@ -292,7 +313,7 @@ DEVFN void ln_row_bwd(float (*red)[MAXW][2], int slot, int wave, int lane, int n
     V8 o = unpack8(res);
 #pragma unroll
     for (int e = 0; e < 8; ++e) o.f[e] = fmaf(rs, g.f[e] - c1 - xh.f[e] * c2, o.f[e]);
-    if (act) *reinterpret_cast<uint4*>(dst) = pack8(o);
+    if (act) stg(dst, pack8(o));
 }
 
 // DUP3: output 3 (x_v) has two consumers; their gradients arrive as dout.p[3] and dout3b (see mix_bwd_kernel in tmix_fused.hip).

@@ -17,23 +17,51 @@
 
 namespace {
 
-constexpr int TPB = 16;      // tokens per workgroup
+constexpr int TPB = 16;      // tokens per workgroup (granularity of the backward kernels' token ranges)
+// Forward kernels: a workgroup owns ceil(ntok / gridDim.x) consecutive tokens.  MANY short-lived workgroups keep more requests in
+// flight than fewer resident ones that walk 16 tokens each (per kernel in profiles/r4_eltwise_micro_ab.jsonl: post -14 % at one token
+// per workgroup, kva -8 % at two; the lerps want four -- the shifted row x[n-1] is the previous iteration's row)
+constexpr int TPB_MIX = 4, TPB_DECAY = 2, TPB_KVA = 2, TPB_POST = 1, TPB_GN = 1;
+DEVFN long own_lo(long ntok) { return (long)blockIdx.x * ((ntok + gridDim.x - 1) / gridDim.x); }
+DEVFN long own_hi(long ntok) { const long t = (ntok + gridDim.x - 1) / gridDim.x, e = ((long)blockIdx.x + 1) * t; return e < ntok ? e : ntok; }
 constexpr int MAXM = 6;
 
 struct V8 { float f[8]; };
 
-DEVFN V8 ld8f(const uint16_t* p) {
-    const uint4 u = *reinterpret_cast<const uint4*>(p);
+// Activation rows are streamed (read once, written once, 172 MB and more per tensor: nothing survives in L2 / MALL until its consumer
+// runs): non-temporal accesses, measured per kernel in profiles/r4_eltwise_micro_ab.jsonl
+#ifndef VRWKV_NT
+#define VRWKV_NT 1
+#endif
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+DEVFN u32x4_t ld8raw(const uint16_t* p) {
+#if VRWKV_NT
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+#else
+    return *reinterpret_cast<const u32x4_t*>(p);
+#endif
+}
+DEVFN V8 cvt8(u32x4_t u) {
     V8 r;
-    r.f[0] = bf16_lo(u.x); r.f[1] = bf16_hi(u.x); r.f[2] = bf16_lo(u.y); r.f[3] = bf16_hi(u.y);
-    r.f[4] = bf16_lo(u.z); r.f[5] = bf16_hi(u.z); r.f[6] = bf16_lo(u.w); r.f[7] = bf16_hi(u.w);
+    r.f[0] = bf16_lo(u[0]); r.f[1] = bf16_hi(u[0]); r.f[2] = bf16_lo(u[1]); r.f[3] = bf16_hi(u[1]);
+    r.f[4] = bf16_lo(u[2]); r.f[5] = bf16_hi(u[2]); r.f[6] = bf16_lo(u[3]); r.f[7] = bf16_hi(u[3]);
     return r;
 }
+DEVFN V8 ld8f(const uint16_t* p) { return cvt8(ld8raw(p)); }
 DEVFN void st8f(uint16_t* p, const V8& v) {
-    *reinterpret_cast<uint4*>(p) = make_uint4(cvt_pk_bf16(v.f[0], v.f[1]), cvt_pk_bf16(v.f[2], v.f[3]),
-                                              cvt_pk_bf16(v.f[4], v.f[5]), cvt_pk_bf16(v.f[6], v.f[7]));
+    const u32x4_t u = {cvt_pk_bf16(v.f[0], v.f[1]), cvt_pk_bf16(v.f[2], v.f[3]), cvt_pk_bf16(v.f[4], v.f[5]), cvt_pk_bf16(v.f[6], v.f[7])};
+#if VRWKV_NT
+    __builtin_nontemporal_store(u, reinterpret_cast<u32x4_t*>(p));
+#else
+    *reinterpret_cast<u32x4_t*>(p) = u;
+#endif
 }
 DEVFN V8 zero8() { V8 r; for (int e = 0; e < 8; ++e) r.f[e] = 0.f; return r; }
+// software-pipelined backward loops (kva_bwd, post_bwd): the NEXT token's raw 16-byte pieces are requested before the current token's
+// arithmetic and stores, converted when used
+#ifndef VRWKV_BWD_PF
+#define VRWKV_BWD_PF 1
+#endif
 // per-workgroup partial of a column sum: part[blockIdx.x][vec][c]
 DEVFN void put_partial(float* part, int nvec, int vec, int C, int c0, const V8& v) {
     float* dst = part + ((size_t)blockIdx.x * nvec + vec) * C + c0;
@@ -89,8 +117,7 @@ __global__ void mix_fwd_kernel(long ntok, int T, int C, const uint16_t* __restri
     V8 m[M];
 #pragma unroll
     for (int i = 0; i < M; ++i) m[i] = ld8f(mu.p[i] + c0);
-    for (long nb = (long)blockIdx.x * TPB; nb < ntok; nb += (long)gridDim.x * TPB)
-    for (long n = nb; n < nb + TPB && n < ntok; ++n) {
+    for (long n = own_lo(ntok), n_end = own_hi(ntok); n < n_end; ++n) {
         const V8 xv = ld8f(x + n * C + c0);
         V8 xx;
         if (n % T != 0) {
@@ -128,14 +155,24 @@ __global__ void mix_fwd_kernel(long ntok, int T, int C, const uint16_t* __restri
 // depend on them, so the unrolled loop keeps many rows in flight.  (Reading row n+1 again for every token, as the
 // first version did, doubled the L2->CU traffic and needed 200+ VGPRs: 1.9 ms per call instead of ~0.4 ms.)
 struct V4 { float f[4]; };
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 DEVFN V4 ld4f(const uint16_t* p) {
-    const uint2 u = *reinterpret_cast<const uint2*>(p);
+#if VRWKV_NT
+    const u32x2_t u = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(p));
+#else
+    const u32x2_t u = *reinterpret_cast<const u32x2_t*>(p);
+#endif
     V4 r;
-    r.f[0] = bf16_lo(u.x); r.f[1] = bf16_hi(u.x); r.f[2] = bf16_lo(u.y); r.f[3] = bf16_hi(u.y);
+    r.f[0] = bf16_lo(u[0]); r.f[1] = bf16_hi(u[0]); r.f[2] = bf16_lo(u[1]); r.f[3] = bf16_hi(u[1]);
     return r;
 }
 DEVFN void st4f(uint16_t* p, const V4& v) {
-    *reinterpret_cast<uint2*>(p) = make_uint2(cvt_pk_bf16(v.f[0], v.f[1]), cvt_pk_bf16(v.f[2], v.f[3]));
+    const u32x2_t u = {cvt_pk_bf16(v.f[0], v.f[1]), cvt_pk_bf16(v.f[2], v.f[3])};
+#if VRWKV_NT
+    __builtin_nontemporal_store(u, reinterpret_cast<u32x2_t*>(p));
+#else
+    *reinterpret_cast<u32x2_t*>(p) = u;
+#endif
 }
 // DUP3: output 3 (x_v of the time-mix) has two consumers (value projection, v-gate LoRA); their gradients arrive as
 // dout.p[3] and dout3b and are summed here instead of by a separate element-wise kernel (3 x 172 MB per layer).
@@ -250,8 +287,7 @@ __global__ void decay_fwd_kernel(long ntok, int C, const uint16_t* __restrict__ 
                                  uint16_t* __restrict__ w) {
     const int c0 = threadIdx.x * 8;
     const V8 b = ld8f(w0 + c0);
-    for (long nb = (long)blockIdx.x * TPB; nb < ntok; nb += (long)gridDim.x * TPB)
-    for (long n = nb; n < nb + TPB && n < ntok; ++n) {
+    for (long n = own_lo(ntok), n_end = own_hi(ntok); n < n_end; ++n) {
         const V8 hv = ld8f(h + n * C + c0);
         V8 o;
 #pragma unroll
@@ -293,8 +329,7 @@ __global__ void kva_fwd_kernel(KvaFwd p) {
     const V8 kk_p = ld8f(p.k_k + c0), ka_p = ld8f(p.k_a + c0), a0 = ld8f(p.a0 + c0);
     V8 v0 = zero8();
     if (p.has_vres) v0 = ld8f(p.v0 + c0);
-    for (long nb = (long)blockIdx.x * TPB; nb < p.ntok; nb += (long)gridDim.x * TPB)
-    for (long n = nb; n < nb + TPB && n < p.ntok; ++n) {
+    for (long n = own_lo(p.ntok), n_end = own_hi(p.ntok); n < n_end; ++n) {
         const long o = n * C + c0;
         const V8 k = ld8f(p.k + o), al = ld8f(p.al + o);
         V8 a, kk, k2, z, b;
@@ -333,19 +368,33 @@ struct KvaBwd {
 // Two passes over the workgroup's token range -- the k / a-gate part, then the value-residual part: they share nothing but the
 // loop, and as one loop the kernel held 4 parameter vectors + 4 gradient accumulators + both parts' rows: 128 VGPRs and 88 B of
 // scratch per lane inside the token loop (3.5 TB/s where post_bwd reaches 5.4).  Per pass: 3 + 3 vectors (1 + 1 in the second).
-__global__ void kva_bwd_kernel(KvaBwd p) {
+template <int LB>
+__global__ __launch_bounds__(LB) void kva_bwd_kernel(KvaBwd p) {
+    constexpr bool PF = VRWKV_BWD_PF && LB <= 256;        // wider rows: 8 or 16 waves per workgroup, the 145 registers of the prefetching loop would leave one workgroup per CU
     const int c0 = threadIdx.x * 8, C = p.C;
     const long lo = range_lo(p.ntok), hi = range_hi(p.ntok);
     {
         const V8 kk_p = ld8f(p.k_k + c0), ka_p = ld8f(p.k_a + c0), a0 = ld8f(p.a0 + c0);
         V8 g_kk = zero8(), g_ka = zero8(), g_a0 = zero8();
+        struct Row { u32x4_t k, al, dk2, dz, db, dk2b; };
+        auto fetch = [&](long n) {
+            const long o = n * C + c0;
+            Row r;
+            r.k = ld8raw(p.k + o); r.al = ld8raw(p.al + o); r.dk2 = ld8raw(p.dk2 + o); r.dz = ld8raw(p.dz + o); r.db = ld8raw(p.db + o);
+            if (p.dk2b) r.dk2b = ld8raw(p.dk2b + o);
+            return r;
+        };
+        Row nxt{};
+        if (PF && lo < hi) nxt = fetch(lo);
         for (long n = lo; n < hi; ++n) {
             const long o = n * C + c0;
-            const V8 k = ld8f(p.k + o), al = ld8f(p.al + o);
-            V8 dk2 = ld8f(p.dk2 + o);
-            const V8 dz = ld8f(p.dz + o), db = ld8f(p.db + o);
+            Row cur;
+            if (PF) { cur = nxt; if (n + 1 < hi) nxt = fetch(n + 1); } else cur = fetch(n);
+            const V8 k = cvt8(cur.k), al = cvt8(cur.al);
+            V8 dk2 = cvt8(cur.dk2);
+            const V8 dz = cvt8(cur.dz), db = cvt8(cur.db);
             if (p.dk2b) {
-                const V8 t = ld8f(p.dk2b + o);
+                const V8 t = cvt8(cur.dk2b);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dk2.f[e] += t.f[e];
             }
@@ -385,12 +434,25 @@ __global__ void kva_bwd_kernel(KvaBwd p) {
     V8 g_v0 = zero8();
     if (p.has_vres) {
         const V8 v0 = ld8f(p.v0 + c0);
+        struct Row2 { u32x4_t v, vf, vl, dv2, dv2b, dvf; };
+        auto fetch2 = [&](long n) {
+            const long o = n * C + c0;
+            Row2 r;
+            r.v = ld8raw(p.v + o); r.vf = ld8raw(p.vfirst + o); r.vl = ld8raw(p.vl + o); r.dv2 = ld8raw(p.dv2 + o);
+            if (p.dv2b) r.dv2b = ld8raw(p.dv2b + o);
+            if (p.dvf_in) r.dvf = ld8raw(p.dvf_in + o);
+            return r;
+        };
+        Row2 nxt{};
+        if (PF && lo < hi) nxt = fetch2(lo);
         for (long n = lo; n < hi; ++n) {
             const long o = n * C + c0;
-            const V8 v = ld8f(p.v + o), vf = ld8f(p.vfirst + o), vl = ld8f(p.vl + o);
-            V8 dv2 = ld8f(p.dv2 + o);
+            Row2 cur;
+            if (PF) { cur = nxt; if (n + 1 < hi) nxt = fetch2(n + 1); } else cur = fetch2(n);
+            const V8 v = cvt8(cur.v), vf = cvt8(cur.vf), vl = cvt8(cur.vl);
+            V8 dv2 = cvt8(cur.dv2);
             if (p.dv2b) {
-                const V8 t = ld8f(p.dv2b + o);
+                const V8 t = cvt8(cur.dv2b);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dv2.f[e] += t.f[e];
             }
@@ -404,7 +466,7 @@ __global__ void kva_bwd_kernel(KvaBwd p) {
                 g_v0.f[e] += dvl.f[e];
             }
             if (p.dvf_in) {                                      // running sum over the layers (autograd would add 3 x 172 MB per layer)
-                const V8 t = ld8f(p.dvf_in + o);
+                const V8 t = cvt8(cur.dvf);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dvf.f[e] += t.f[e];
             }
@@ -423,8 +485,7 @@ struct PostFwd {
 __global__ void post_fwd_kernel(PostFwd p) {
     const int c0 = threadIdx.x * 8, C = p.C;
     const V8 lw = ld8f(p.ln_w + c0), lb = ld8f(p.ln_b + c0), rk = ld8f(p.r_k + c0);
-    for (long nb = (long)blockIdx.x * TPB; nb < p.ntok; nb += (long)gridDim.x * TPB)
-    for (long n = nb; n < nb + TPB && n < p.ntok; ++n) {
+    for (long n = own_lo(p.ntok), n_end = own_hi(p.ntok); n < n_end; ++n) {
         const long o = n * C + c0;
         const V8 y = ld8f(p.y + o), r = ld8f(p.r + o), k = ld8f(p.k + o), v = ld8f(p.v + o), g = ld8f(p.g + o);
         float s1 = 0.f, sb = 0.f;
@@ -451,8 +512,7 @@ __global__ void gn_silu_fwd_kernel(long ntok, int C, float eps, const uint16_t* 
                                    const uint16_t* __restrict__ ln_w, const uint16_t* __restrict__ ln_b, uint16_t* __restrict__ outp) {
     const int c0 = threadIdx.x * 8;
     const V8 lw = ld8f(ln_w + c0), lb = ld8f(ln_b + c0);
-    for (long nb = (long)blockIdx.x * TPB; nb < ntok; nb += (long)gridDim.x * TPB)
-    for (long n = nb; n < nb + TPB && n < ntok; ++n) {
+    for (long n = own_lo(ntok), n_end = own_hi(ntok); n < n_end; ++n) {
         const long o = n * C + c0;
         const V8 y = ld8f(yp + o), gg = ld8f(ggp + o);
         float s1 = 0.f;
@@ -516,14 +576,28 @@ struct PostBwd {
     uint16_t *dy, *dr, *dk, *dv, *dg;
     float* part;                                       // [grid][3][C] partials of dln_w dln_b dr_k
 };
-__global__ void post_bwd_kernel(PostBwd p) {
+template <int LB>
+__global__ __launch_bounds__(LB) void post_bwd_kernel(PostBwd p) {
+    constexpr bool PF = VRWKV_BWD_PF && LB <= 256;
     const int c0 = threadIdx.x * 8, C = p.C;
     const V8 lw = ld8f(p.ln_w + c0), lb = ld8f(p.ln_b + c0), rk = ld8f(p.r_k + c0);
     V8 g_w = zero8(), g_b = zero8(), g_rk = zero8();
-    for (long n = range_lo(p.ntok), hi = range_hi(p.ntok); n < hi; ++n) {
+    struct Row { u32x4_t y, r, k, v, g, d; };
+    auto fetch = [&](long n) {
         const long o = n * C + c0;
-        const V8 y = ld8f(p.y + o), r = ld8f(p.r + o), k = ld8f(p.k + o), v = ld8f(p.v + o), g = ld8f(p.g + o);
-        const V8 d = ld8f(p.dout + o);
+        Row q;
+        q.y = ld8raw(p.y + o); q.r = ld8raw(p.r + o); q.k = ld8raw(p.k + o); q.v = ld8raw(p.v + o); q.g = ld8raw(p.g + o); q.d = ld8raw(p.dout + o);
+        return q;
+    };
+    const long lo = range_lo(p.ntok), hi = range_hi(p.ntok);
+    Row nxt{};
+    if (PF && lo < hi) nxt = fetch(lo);
+    for (long n = lo; n < hi; ++n) {
+        const long o = n * C + c0;
+        Row cur;
+        if (PF) { cur = nxt; if (n + 1 < hi) nxt = fetch(n + 1); } else cur = fetch(n);
+        const V8 y = cvt8(cur.y), r = cvt8(cur.r), k = cvt8(cur.k), v = cvt8(cur.v), g = cvt8(cur.g);
+        const V8 d = cvt8(cur.d);
         float s1 = 0.f, sb = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s1 += y.f[e]; sb = fmaf(r.f[e] * k.f[e], rk.f[e], sb); }
@@ -565,29 +639,44 @@ __global__ void post_bwd_kernel(PostBwd p) {
 }
 
 // ---------------------------------------------------------------------------------------------- F6: relu^2
+// One 16-byte vector per thread, no loop, non-temporal accesses: the same arithmetic as a grid-stride loop over <= 4096 workgroups
+// ran at 4.8-5.1 TB/s, this form at 6.5 (benchmarks/eltwise_probe.hip, profiles/r4_eltwise_probe.jsonl) -- a wave that issues
+// its loads, its store and ends keeps more requests in flight per CU than a resident wave that waits for its own store every
+// iteration.
 __global__ __launch_bounds__(256) void relusq_fwd_kernel(long n8, const uint16_t* __restrict__ h, uint16_t* __restrict__ y) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
-        V8 v = ld8f(h + i * 8);
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    V8 v = ld8f(h + i * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float r = fmaxf(v.f[e], 0.f); v.f[e] = r * r; }
-        st8f(y + i * 8, v);
-    }
+    for (int e = 0; e < 8; ++e) { const float r = fmaxf(v.f[e], 0.f); v.f[e] = r * r; }
+    st8f(y + i * 8, v);
 }
 __global__ __launch_bounds__(256) void relusq_bwd_kernel(long n8, const uint16_t* __restrict__ h, const uint16_t* __restrict__ dy,
                                                          uint16_t* __restrict__ dh) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
-        const V8 v = ld8f(h + i * 8), d = ld8f(dy + i * 8);
-        V8 o;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const V8 v = ld8f(h + i * 8), d = ld8f(dy + i * 8);
+    V8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o.f[e] = 2.f * fmaxf(v.f[e], 0.f) * d.f[e];
-        st8f(dh + i * 8, o);
-    }
+    for (int e = 0; e < 8; ++e) o.f[e] = 2.f * fmaxf(v.f[e], 0.f) * d.f[e];
+    st8f(dh + i * 8, o);
 }
 
 inline int ok_c(int C) { return C > 0 && C % 64 == 0 && C / 8 <= 1024; }
-inline dim3 tok_grid(long ntok) { return dim3((unsigned)((ntok + TPB - 1) / TPB)); }
-constexpr int BWD_GRID = 1024;         // workgroups (= partial rows) of the backward kernels: 4 per CU
+inline dim3 tok_grid(long ntok, int tpb) { return dim3((unsigned)((ntok + tpb - 1) / tpb)); }
+#ifndef VRWKV_BWD_GRID
+#define VRWKV_BWD_GRID 1024
+#endif
+constexpr int BWD_GRID = VRWKV_BWD_GRID;         // workgroups (= partial rows) of the backward kernels: 4 per CU
 inline int bwd_grid(long ntok) { long g = (ntok + TPB - 1) / TPB; return (int)(g < BWD_GRID ? g : BWD_GRID); }
+// kva_bwd / post_bwd with the prefetched row: 138-145 registers, three workgroups of 256 threads per CU -> one round of 768
+#ifndef VRWKV_BWD_GRID_PF
+#define VRWKV_BWD_GRID_PF 768
+#endif
+inline int bwd_grid_pf(long ntok, int C) {
+    const int g = bwd_grid(ntok), cap = (VRWKV_BWD_PF && C / 8 <= 256) ? VRWKV_BWD_GRID_PF : BWD_GRID;
+    return g < cap ? g : cap;
+}
 inline void colsum(int G, long width, const float* part, float* out, hipStream_t st) {
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)(width / 16)), dim3(256), 0, st, G, width, part, out);
 }
@@ -608,9 +697,9 @@ int vrwkv_mix_fwd_prev_bf16(long ntok, int T, int C, int M, const void* x, const
     Ptrs6 m{}; MPtrs6 o{};
     for (int i = 0; i < M; ++i) { m.p[i] = (const uint16_t*)mu[i]; o.p[i] = (uint16_t*)out[i]; if (!m.p[i] || !o.p[i]) return VRWKV_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
-    if (M == 6) hipLaunchKernelGGL(mix_fwd_kernel<6>, tok_grid(ntok), dim3(C / 8), 0, st, ntok, T, C, (const uint16_t*)x, (const uint16_t*)x_prev, m, o, Ptrs6{});
-    else if (M == 2) hipLaunchKernelGGL(mix_fwd_kernel<2>, tok_grid(ntok), dim3(C / 8), 0, st, ntok, T, C, (const uint16_t*)x, (const uint16_t*)x_prev, m, o, Ptrs6{});
-    else hipLaunchKernelGGL(mix_fwd_kernel<1>, tok_grid(ntok), dim3(C / 8), 0, st, ntok, T, C, (const uint16_t*)x, (const uint16_t*)x_prev, m, o, Ptrs6{});
+    if (M == 6) hipLaunchKernelGGL(mix_fwd_kernel<6>, tok_grid(ntok, TPB_MIX), dim3(C / 8), 0, st, ntok, T, C, (const uint16_t*)x, (const uint16_t*)x_prev, m, o, Ptrs6{});
+    else if (M == 2) hipLaunchKernelGGL(mix_fwd_kernel<2>, tok_grid(ntok, TPB_MIX), dim3(C / 8), 0, st, ntok, T, C, (const uint16_t*)x, (const uint16_t*)x_prev, m, o, Ptrs6{});
+    else hipLaunchKernelGGL(mix_fwd_kernel<1>, tok_grid(ntok, TPB_MIX), dim3(C / 8), 0, st, ntok, T, C, (const uint16_t*)x, (const uint16_t*)x_prev, m, o, Ptrs6{});
     return done();
 }
 
@@ -668,7 +757,7 @@ int vrwkv_ddmix_fwd_bf16(long ntok, int T, int C, const void* x, const void* con
         m.p[i] = (const uint16_t*)mu[i]; t.p[i] = (const uint16_t*)mm[i]; o.p[i] = (uint16_t*)out[i];
         if (!m.p[i] || !t.p[i] || !o.p[i]) return VRWKV_EINVAL;
     }
-    hipLaunchKernelGGL((mix_fwd_kernel<5, true>), tok_grid(ntok), dim3(C / 8), 0, (hipStream_t)stream, ntok, T, C, (const uint16_t*)x,
+    hipLaunchKernelGGL((mix_fwd_kernel<5, true>), tok_grid(ntok, TPB_MIX), dim3(C / 8), 0, (hipStream_t)stream, ntok, T, C, (const uint16_t*)x,
                        (const uint16_t*)nullptr, m, o, t);
     return done();
 }
@@ -695,7 +784,7 @@ int vrwkv_ddmix_bwd_bf16(long ntok, int T, int C, const void* x, const void* con
 int vrwkv_gn_silu_fwd_bf16(long ntok, int C, float eps, const void* y, const void* gg, const void* ln_w, const void* ln_b, void* out, void* stream) {
     if (ntok <= 0 || !y || !gg || !ln_w || !ln_b || !out) return VRWKV_EINVAL;
     if (!ok_c(C)) return VRWKV_ESHAPE;
-    hipLaunchKernelGGL(gn_silu_fwd_kernel, tok_grid(ntok), dim3(C / 8), 0, (hipStream_t)stream, ntok, C, eps, (const uint16_t*)y, (const uint16_t*)gg,
+    hipLaunchKernelGGL(gn_silu_fwd_kernel, tok_grid(ntok, TPB_GN), dim3(C / 8), 0, (hipStream_t)stream, ntok, C, eps, (const uint16_t*)y, (const uint16_t*)gg,
                        (const uint16_t*)ln_w, (const uint16_t*)ln_b, (uint16_t*)out);
     return done();
 }
@@ -714,7 +803,7 @@ int vrwkv_gn_silu_bwd_bf16(long ntok, int C, float eps, const void* y, const voi
 int vrwkv_decay_fwd_bf16(long ntok, int C, const void* h, const void* w0, void* w, void* stream) {
     if (ntok <= 0 || !h || !w0 || !w) return VRWKV_EINVAL;
     if (!ok_c(C)) return VRWKV_ESHAPE;
-    hipLaunchKernelGGL(decay_fwd_kernel, tok_grid(ntok), dim3(C / 8), 0, (hipStream_t)stream, ntok, C, (const uint16_t*)h, (const uint16_t*)w0, (uint16_t*)w);
+    hipLaunchKernelGGL(decay_fwd_kernel, tok_grid(ntok, TPB_DECAY), dim3(C / 8), 0, (hipStream_t)stream, ntok, C, (const uint16_t*)h, (const uint16_t*)w0, (uint16_t*)w);
     return done();
 }
 int vrwkv_decay_bwd_bf16(long ntok, int C, const void* h, const void* w0, const void* dw, void* dh, float* dw0, float* ws, void* stream) {
@@ -736,7 +825,7 @@ int vrwkv_kva_fwd_bf16(long ntok, int C, int has_vres, const void* k, const void
     KvaFwd p{ntok, C, has_vres, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)vfirst, (const uint16_t*)vl, (const uint16_t*)al,
              (const uint16_t*)k_k, (const uint16_t*)k_a, (const uint16_t*)a0, (const uint16_t*)v0,
              (uint16_t*)k2, (uint16_t*)v2, (uint16_t*)z, (uint16_t*)b};
-    hipLaunchKernelGGL(kva_fwd_kernel, tok_grid(ntok), dim3(C / 8), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kva_fwd_kernel, tok_grid(ntok, TPB_KVA), dim3(C / 8), 0, (hipStream_t)stream, p);
     return done();
 }
 int vrwkv_kva_bwd_bf16(long ntok, int C, int has_vres, const void* k, const void* v, const void* vfirst, const void* vl, const void* al,
@@ -771,8 +860,10 @@ int vrwkv_kva_bwd3_bf16(long ntok, int C, int has_vres, const void* k, const voi
              (const uint16_t*)dk2, (const uint16_t*)dv2, (const uint16_t*)dz, (const uint16_t*)db,
              (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dvfirst, (uint16_t*)dvl, (uint16_t*)dal, ws,
              (const uint16_t*)dk2_second, (const uint16_t*)dv2_second, (const uint16_t*)dvfirst_in};
-    const int G = bwd_grid(ntok);
-    hipLaunchKernelGGL(kva_bwd_kernel, dim3(G), dim3(C / 8), 0, (hipStream_t)stream, p);
+    const int G = bwd_grid_pf(ntok, C);
+    if (C / 8 <= 256) hipLaunchKernelGGL(kva_bwd_kernel<256>, dim3(G), dim3(C / 8), 0, (hipStream_t)stream, p);
+    else if (C / 8 <= 512) hipLaunchKernelGGL(kva_bwd_kernel<512>, dim3(G), dim3(C / 8), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(kva_bwd_kernel<1024>, dim3(G), dim3(C / 8), 0, (hipStream_t)stream, p);
     colsum(G, 4L * C, ws, dparams, (hipStream_t)stream);       // dparams = [dk_k | dk_a | da0 | dv0], C floats each
     return done();
 }
@@ -783,7 +874,7 @@ int vrwkv_post_fwd_bf16(long ntok, int C, float eps, const void* y, const void* 
     if (!ok_c(C)) return VRWKV_ESHAPE;
     PostFwd p{ntok, C, eps, (const uint16_t*)y, (const uint16_t*)r, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)g,
               (const uint16_t*)ln_w, (const uint16_t*)ln_b, (const uint16_t*)r_k, (uint16_t*)out};
-    hipLaunchKernelGGL(post_fwd_kernel, tok_grid(ntok), dim3(C / 8), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(post_fwd_kernel, tok_grid(ntok, TPB_POST), dim3(C / 8), 0, (hipStream_t)stream, p);
     return done();
 }
 int vrwkv_post_bwd_bf16(long ntok, int C, float eps, const void* y, const void* r, const void* k, const void* v, const void* g,
@@ -795,8 +886,10 @@ int vrwkv_post_bwd_bf16(long ntok, int C, float eps, const void* y, const void* 
     PostBwd p{ntok, C, eps, (const uint16_t*)y, (const uint16_t*)r, (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)g,
               (const uint16_t*)ln_w, (const uint16_t*)ln_b, (const uint16_t*)r_k, (const uint16_t*)dout,
               (uint16_t*)dy, (uint16_t*)dr, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dg, ws};
-    const int G = bwd_grid(ntok);
-    hipLaunchKernelGGL(post_bwd_kernel, dim3(G), dim3(C / 8), 0, (hipStream_t)stream, p);
+    const int G = bwd_grid_pf(ntok, C);
+    if (C / 8 <= 256) hipLaunchKernelGGL(post_bwd_kernel<256>, dim3(G), dim3(C / 8), 0, (hipStream_t)stream, p);
+    else if (C / 8 <= 512) hipLaunchKernelGGL(post_bwd_kernel<512>, dim3(G), dim3(C / 8), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(post_bwd_kernel<1024>, dim3(G), dim3(C / 8), 0, (hipStream_t)stream, p);
     colsum(G, 3L * C, ws, dparams, (hipStream_t)stream);       // dparams = [dln_w | dln_b | dr_k]
     return done();
 }
@@ -805,7 +898,8 @@ int vrwkv_relusq_fwd_bf16(long n, const void* h, void* y, void* stream) {
     if (n <= 0 || !h || !y) return VRWKV_EINVAL;
     if (n % 8 != 0) return VRWKV_ESHAPE;
     const long n8 = n / 8;
-    long blocks = (n8 + 255) / 256; if (blocks > 4096) blocks = 4096;
+    const long blocks = (n8 + 255) / 256;
+    if (blocks > 0x7fffffffL) return VRWKV_ESHAPE;
     hipLaunchKernelGGL(relusq_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n8, (const uint16_t*)h, (uint16_t*)y);
     return done();
 }
@@ -813,7 +907,8 @@ int vrwkv_relusq_bwd_bf16(long n, const void* h, const void* dy, void* dh, void*
     if (n <= 0 || !h || !dy || !dh) return VRWKV_EINVAL;
     if (n % 8 != 0) return VRWKV_ESHAPE;
     const long n8 = n / 8;
-    long blocks = (n8 + 255) / 256; if (blocks > 4096) blocks = 4096;
+    const long blocks = (n8 + 255) / 256;
+    if (blocks > 0x7fffffffL) return VRWKV_ESHAPE;
     hipLaunchKernelGGL(relusq_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n8, (const uint16_t*)h, (const uint16_t*)dy, (uint16_t*)dh);
     return done();
 }
