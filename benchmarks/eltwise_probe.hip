@@ -46,6 +46,35 @@ __global__ __launch_bounds__(256) void k_flat(long n, const u32x4* __restrict__ 
         if (NT) __builtin_nontemporal_store(r, o + base + q * 256); else o[base + q * 256] = r;
     }
 }
+// ---- a token-row kernel with post_bwd's access mix: 6 rows read, 5 written per token (C = 2048: 256 threads x 16 B), trivial arithmetic.
+// MODE 0: contiguous token range per workgroup (G workgroups), 1: tokens blockIdx.x + k G, 2: the same with the next token's rows
+// requested before the current token's stores, 3: one token per workgroup (G = ntok)
+struct Rows { const u32x4* in[6]; u32x4* out[5]; };
+template <int MODE, bool NT>
+__global__ __launch_bounds__(256) void k_rows(long ntok, Rows p) {
+    const long G = gridDim.x;
+    long lo, hi, step;
+    if (MODE == 0) { lo = ntok * blockIdx.x / G; hi = ntok * (blockIdx.x + 1) / G; step = 1; }
+    else { lo = blockIdx.x; hi = ntok; step = G; }
+    auto ld = [&](int a, long n) { const u32x4* q = p.in[a] + n * 256 + threadIdx.x; return NT ? __builtin_nontemporal_load(q) : *q; };
+    u32x4 nx[6];
+    if (MODE == 2) for (int a = 0; a < 6; ++a) nx[a] = ld(a, lo);
+    for (long n = lo; n < hi; n += step) {
+        u32x4 v[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) v[a] = MODE == 2 ? nx[a] : ld(a, n);
+        if (MODE == 2 && n + step < hi) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) nx[a] = ld(a, n + step);
+        }
+#pragma unroll
+        for (int a = 0; a < 5; ++a) {
+            const u32x4 r = f_bwd(v[a], v[a + 1]);
+            u32x4* q = p.out[a] + n * 256 + threadIdx.x;
+            if (NT) __builtin_nontemporal_store(r, q); else *q = r;
+        }
+    }
+}
 template <class F>
 static void run(const char* name, long bytes, F launch) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -74,5 +103,23 @@ int main() {
     FLAT(false, 1, true, "relusq fwd 1 vector / thread nontemporal") FLAT(false, 4, true, "relusq fwd 4 vectors / thread nontemporal")
     FLAT(true, 1, false, "relusq bwd 1 vector / thread") FLAT(true, 2, false, "relusq bwd 2 vectors / thread") FLAT(true, 4, false, "relusq bwd 4 vectors / thread")
     FLAT(true, 1, true, "relusq bwd 1 vector / thread nontemporal") FLAT(true, 4, true, "relusq bwd 4 vectors / thread nontemporal")
+    {
+        const long ntok = 41984;
+        Rows r;
+        u32x4* buf;
+        hipMalloc(&buf, 11 * ntok * 256 * 16);
+        hipMemset(buf, 0x3e, 11 * ntok * 256 * 16);
+        for (int a = 0; a < 6; ++a) r.in[a] = buf + (long)a * ntok * 256;
+        for (int a = 0; a < 5; ++a) r.out[a] = buf + (long)(6 + a) * ntok * 256;
+        const long bytes = 11 * ntok * 256 * 16;
+#define ROWS(MODE, NT, G, label) run(label, bytes, [&] { hipLaunchKernelGGL((k_rows<MODE, NT>), dim3(G), dim3(256), 0, 0, ntok, r); });
+        ROWS(0, false, 1024, "rows 6r5w: contiguous ranges, 1024 wg") ROWS(0, true, 1024, "rows 6r5w: contiguous ranges, 1024 wg, nontemporal")
+        ROWS(0, true, 2048, "rows 6r5w: contiguous ranges, 2048 wg, nontemporal")
+        ROWS(1, true, 1024, "rows 6r5w: strided tokens, 1024 wg, nontemporal") ROWS(2, true, 1024, "rows 6r5w: strided tokens + prefetch, 1024 wg, nontemporal")
+        ROWS(2, true, 2048, "rows 6r5w: strided tokens + prefetch, 2048 wg, nontemporal")
+        ROWS(3, false, 41984, "rows 6r5w: one token per wg") ROWS(3, true, 41984, "rows 6r5w: one token per wg, nontemporal")
+        ROWS(1, true, 10496, "rows 6r5w: strided, 4 tokens per wg, nontemporal") ROWS(1, true, 5248, "rows 6r5w: strided, 8 tokens per wg, nontemporal")
+        ROWS(0, true, 10496, "rows 6r5w: contiguous, 4 tokens per wg, nontemporal") ROWS(0, true, 5248, "rows 6r5w: contiguous, 8 tokens per wg, nontemporal")
+    }
     return 0;
 }

@@ -102,6 +102,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(int G, long width, const fl
 // token (a 16-token tile grid left 2 or 3 tiles per workgroup at the benchmark shape: 15 % idle).
 DEVFN long range_lo(long ntok) { return ntok * blockIdx.x / gridDim.x; }
 DEVFN long range_hi(long ntok) { return ntok * (blockIdx.x + 1) / gridDim.x; }
+// kva_bwd / post_bwd (token-local arithmetic): tokens blockIdx.x, blockIdx.x + gridDim.x, ... instead of a contiguous range
+#ifndef VRWKV_BWD_STRIDED
+#define VRWKV_BWD_STRIDED 1
+#endif
+DEVFN long tok_first(long ntok) { return VRWKV_BWD_STRIDED ? (long)blockIdx.x : range_lo(ntok); }
+DEVFN long tok_end(long ntok) { return VRWKV_BWD_STRIDED ? ntok : range_hi(ntok); }
+DEVFN long tok_step() { return VRWKV_BWD_STRIDED ? (long)gridDim.x : 1L; }
 DEVFN float sigmoidf_(float x) { return 1.f / (1.f + fast_exp(-x)); }
 
 struct Ptrs6 { const uint16_t* p[MAXM]; };
@@ -372,7 +379,7 @@ template <int LB>
 __global__ __launch_bounds__(LB) void kva_bwd_kernel(KvaBwd p) {
     constexpr bool PF = VRWKV_BWD_PF && LB <= 256;        // wider rows: 8 or 16 waves per workgroup, the 145 registers of the prefetching loop would leave one workgroup per CU
     const int c0 = threadIdx.x * 8, C = p.C;
-    const long lo = range_lo(p.ntok), hi = range_hi(p.ntok);
+    const long lo = tok_first(p.ntok), hi = tok_end(p.ntok), step = tok_step();
     {
         const V8 kk_p = ld8f(p.k_k + c0), ka_p = ld8f(p.k_a + c0), a0 = ld8f(p.a0 + c0);
         V8 g_kk = zero8(), g_ka = zero8(), g_a0 = zero8();
@@ -386,10 +393,10 @@ __global__ __launch_bounds__(LB) void kva_bwd_kernel(KvaBwd p) {
         };
         Row nxt{};
         if (PF && lo < hi) nxt = fetch(lo);
-        for (long n = lo; n < hi; ++n) {
+        for (long n = lo; n < hi; n += step) {
             const long o = n * C + c0;
             Row cur;
-            if (PF) { cur = nxt; if (n + 1 < hi) nxt = fetch(n + 1); } else cur = fetch(n);
+            if (PF) { cur = nxt; if (n + step < hi) nxt = fetch(n + step); } else cur = fetch(n);
             const V8 k = cvt8(cur.k), al = cvt8(cur.al);
             V8 dk2 = cvt8(cur.dk2);
             const V8 dz = cvt8(cur.dz), db = cvt8(cur.db);
@@ -445,10 +452,10 @@ __global__ __launch_bounds__(LB) void kva_bwd_kernel(KvaBwd p) {
         };
         Row2 nxt{};
         if (PF && lo < hi) nxt = fetch2(lo);
-        for (long n = lo; n < hi; ++n) {
+        for (long n = lo; n < hi; n += step) {
             const long o = n * C + c0;
             Row2 cur;
-            if (PF) { cur = nxt; if (n + 1 < hi) nxt = fetch2(n + 1); } else cur = fetch2(n);
+            if (PF) { cur = nxt; if (n + step < hi) nxt = fetch2(n + step); } else cur = fetch2(n);
             const V8 v = cvt8(cur.v), vf = cvt8(cur.vf), vl = cvt8(cur.vl);
             V8 dv2 = cvt8(cur.dv2);
             if (p.dv2b) {
@@ -589,13 +596,13 @@ __global__ __launch_bounds__(LB) void post_bwd_kernel(PostBwd p) {
         q.y = ld8raw(p.y + o); q.r = ld8raw(p.r + o); q.k = ld8raw(p.k + o); q.v = ld8raw(p.v + o); q.g = ld8raw(p.g + o); q.d = ld8raw(p.dout + o);
         return q;
     };
-    const long lo = range_lo(p.ntok), hi = range_hi(p.ntok);
+    const long lo = tok_first(p.ntok), hi = tok_end(p.ntok), step = tok_step();
     Row nxt{};
     if (PF && lo < hi) nxt = fetch(lo);
-    for (long n = lo; n < hi; ++n) {
+    for (long n = lo; n < hi; n += step) {
         const long o = n * C + c0;
         Row cur;
-        if (PF) { cur = nxt; if (n + 1 < hi) nxt = fetch(n + 1); } else cur = fetch(n);
+        if (PF) { cur = nxt; if (n + step < hi) nxt = fetch(n + step); } else cur = fetch(n);
         const V8 y = cvt8(cur.y), r = cvt8(cur.r), k = cvt8(cur.k), v = cvt8(cur.v), g = cvt8(cur.g);
         const V8 d = cvt8(cur.d);
         float s1 = 0.f, sb = 0.f;
