@@ -84,6 +84,9 @@ int vrwkv_wkv6_forward_bf16(int B, int T, int C, int H, const void* r, const voi
 int vrwkv_wkv6_backward_bf16(int B, int T, int C, int H, const void* r, const void* k, const void* v, const float* ew,
                              const void* u, const void* gy, const float* s_ckpt, void* gr, void* gk, void* gv, void* gw,
                              void* gu, void* stream);
+/* Kernel generation of the WKV6 backward (same-box A/B in benchmarks): -1 = default (2), 2 = three-role pipeline of 12 waves
+ * (csrc/wkv6_bwd_v2.h), 1 = the four-wave kernel of rounds 1-3 (csrc/wkv6_chunked.h).  Anything else: VRWKV_EINVAL. */
+int vrwkv_wkv6_set_backward_variant(int variant);
 
 /* Residual add + LayerNorm in one pass (Block.forward: x = x + att(ln1(x)); x = x + ffn(ln2(x)), and ln_out --
  * VisualRWKV-v7/v7.00/src/model.py:247-254,318; the reference runs a bf16 add followed by nn.LayerNorm).

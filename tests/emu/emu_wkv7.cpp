@@ -10,6 +10,7 @@
 #include <wkv7_bwd_v8.h>
 #include <wkv7_bwd_v5.h>
 #include <wkv6_chunked.h>
+#include <wkv6_bwd_v2.h>
 
 extern "C" {
 
@@ -63,6 +64,14 @@ int emu_wkv6_backward(int B, int T, int H, const void* r, const void* k, const v
                       (const uint16_t*)gy, s, (uint16_t*)gr, (uint16_t*)gk, (uint16_t*)gv, (uint16_t*)gw, (uint16_t*)gu};
     emu::launch(dim3((unsigned)(B * H)), dim3(256), [&] { wkv6c::bwd6_kernel(p); });
     return (int)sizeof(wkv6c::Lds6B);
+}
+
+int emu_wkv6_backward_v2(int B, int T, int H, const void* r, const void* k, const void* v, const float* ew, const void* u,
+                         const void* gy, const float* s, void* gr, void* gk, void* gv, void* gw, void* gu) {
+    wkv6c::Bwd6Args p{T, H, (const uint16_t*)r, (const uint16_t*)k, (const uint16_t*)v, ew, (const uint16_t*)u,
+                      (const uint16_t*)gy, s, (uint16_t*)gr, (uint16_t*)gk, (uint16_t*)gv, (uint16_t*)gw, (uint16_t*)gu};
+    emu::launch(dim3((unsigned)(B * H)), dim3(768), [&] { wkv6v2::bwd6_kernel_v2(p); });       // three-role pipeline
+    return (int)sizeof(wkv6v2::Lds6V2);
 }
 
 }  // extern "C"

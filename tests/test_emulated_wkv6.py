@@ -30,8 +30,9 @@ def test_forward(emu_lib, B, T, H):
         assert rel_rms(got, S) < 2e-5 if c else float(got.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("B,T,H", [(1, 16, 1), (2, 37, 2), (1, 80, 1)])
-def test_backward(emu_lib, B, T, H):
+def test_backward(emu_lib, B, T, H, variant):
     r, k, v, w, u, gy = make_inputs6(B, T, H, seed=100 + T)
     ew = (-torch.exp(w.float())).contiguous()
     y = torch.zeros_like(r)
@@ -40,8 +41,9 @@ def test_backward(emu_lib, B, T, H):
     emu_lib.emu_wkv6_forward(B, T, H, P(r), P(k), P(v), P(ew), P(u), P(y), P(s))
     outs = [torch.zeros_like(r) for _ in range(4)]
     gu = torch.zeros(B, H * 64, dtype=torch.bfloat16)
-    lds = emu_lib.emu_wkv6_backward(B, T, H, P(r), P(k), P(v), P(ew), P(u), P(gy), P(s), *[P(o) for o in outs], P(gu))
-    assert 0 < lds <= 64 * 1024
+    entry = emu_lib.emu_wkv6_backward if variant == 1 else emu_lib.emu_wkv6_backward_v2      # four waves | three-role pipeline of twelve
+    lds = entry(B, T, H, P(r), P(k), P(v), P(ew), P(u), P(gy), P(s), *[P(o) for o in outs], P(gu))
+    assert 0 < lds <= (64 if variant == 1 else 160) * 1024
     _, (gr, gk, gv, gw, gu_ref) = wkv6_autograd(r, k, v, w, u, gy)
     for name, o, ref in zip(["gr", "gk", "gv", "gw"], outs, (gr, gk, gv, gw)):
         assert rel_rms(o.double(), ref) < 4e-3, name                  # one bf16 rounding

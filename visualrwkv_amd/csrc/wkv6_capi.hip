@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include "../../include/visualrwkv_hip.h"
 #include <wkv6_chunked.h>
+#include <wkv6_bwd_v2.h>
 
 namespace {
 inline bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
@@ -12,10 +13,17 @@ inline int check6(int B, int T, int C, int H) {
     if (C != H * 64) return VRWKV_ESHAPE;               // head size 64 (RWKV_HEAD_SIZE_A, -D_N_=64 in the reference build)
     return VRWKV_OK;
 }
+int g_bwd6_variant = -1;            // -1: default (2); 1: bwd6_kernel (wkv6_chunked.h), 2: bwd6_kernel_v2 (wkv6_bwd_v2.h)
 inline int done6() { hipError_t e = hipGetLastError(); return e == hipSuccess ? VRWKV_OK : (int)e; }
 }  // namespace
 
 extern "C" {
+
+int vrwkv_wkv6_set_backward_variant(int variant) {
+    if (variant != -1 && variant != 1 && variant != 2) return VRWKV_EINVAL;
+    g_bwd6_variant = variant;
+    return VRWKV_OK;
+}
 
 long vrwkv_wkv6_ckpt_floats(int B, int T, int H) {
     if (B <= 0 || T <= 0 || H <= 0) return 0;
@@ -46,7 +54,14 @@ int vrwkv_wkv6_backward_bf16(int B, int T, int C, int H, const void* r, const vo
         return VRWKV_EALIGN;
     wkv6c::Bwd6Args p{T, H, (const uint16_t*)r, (const uint16_t*)k, (const uint16_t*)v, ew, (const uint16_t*)u,
                       (const uint16_t*)gy, s_ckpt, (uint16_t*)gr, (uint16_t*)gk, (uint16_t*)gv, (uint16_t*)gw, (uint16_t*)gu};
-    hipLaunchKernelGGL(wkv6c::bwd6_kernel, dim3((unsigned)((long)B * H)), dim3(256), 0, (hipStream_t)stream, p);
+    if (g_bwd6_variant == 1) {
+        hipLaunchKernelGGL(wkv6c::bwd6_kernel, dim3((unsigned)((long)B * H)), dim3(256), 0, (hipStream_t)stream, p);
+        return done6();
+    }
+    void (*kern)(wkv6c::Bwd6Args) = &wkv6v2::bwd6_kernel_v2;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv6v2::Lds6V2));
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((long)B * H)), dim3(768), sizeof(wkv6v2::Lds6V2), (hipStream_t)stream, p);
     return done6();
 }
 

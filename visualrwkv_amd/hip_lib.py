@@ -24,6 +24,7 @@ PROTOTYPES = {
     "vrwkv_wkv6_ckpt_floats": (_c_long, [_c_int] * 3),
     "vrwkv_wkv6_forward_bf16": (_c_int, [_c_int] * 4 + [_c_void_p] * 8),
     "vrwkv_wkv6_backward_bf16": (_c_int, [_c_int] * 4 + [_c_void_p] * 13),
+    "vrwkv_wkv6_set_backward_variant": (_c_int, [_c_int]),
     "vrwkv_add_ln_ws_floats": (_c_long, [_c_long, _c_int]),
     "vrwkv_add_ln_fwd_bf16": (_c_int, [_c_long, _c_int, _c_float] + [_c_void_p] * 9),
     "vrwkv_add_ln_scaled_fwd_bf16": (_c_int, [_c_long, _c_int, _c_float] + [_c_void_p] * 8),

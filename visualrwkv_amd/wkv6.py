@@ -9,6 +9,8 @@ sizes a per-thread array with -D_T_=ctx_len).  CPU tensors raise: there is no CP
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import hip_lib
@@ -72,6 +74,13 @@ def backward_hip(B, T, C, H, r, k, v, ew, u, gy, gr, gk, gv, gw, gu, ckpt=None):
     hip_lib.check(rc, "vrwkv_wkv6_backward_bf16")
 
 
+def _apply_variant_env():
+    """VRWKV_WKV6_BWD_VARIANT: same-box A/B of the backward kernel generations (benchmarks only)."""
+    v = os.environ.get("VRWKV_WKV6_BWD_VARIANT")
+    if v is not None:
+        hip_lib.check(hip_lib.load().vrwkv_wkv6_set_backward_variant(int(v)), "vrwkv_wkv6_set_backward_variant")
+
+
 def _register():
     lib = torch.library.Library("wkv6", "DEF")
     lib.define(_FWD_SCHEMA)
@@ -88,6 +97,7 @@ def _register():
 
 
 _LIB = _register()
+_apply_variant_env()
 
 
 class WKV_6(torch.autograd.Function):
