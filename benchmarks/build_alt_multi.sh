@@ -3,7 +3,7 @@
 # selected at run time with VRWKV_HIP_LIB=...).   bash benchmarks/build_alt_multi.sh <name> "<flags>" <source.hip> [<source.hip> ...]
 set -e
 R=$(cd $(dirname $0)/.. && pwd); NAME=$1; FLAGS=$2; shift; shift
-python -m visualrwkv_amd.build > /dev/null
+python -c "from visualrwkv_amd import build; build.build()" > /dev/null 2>&1
 mkdir -p $R/benchmarks/_alt
 OBJS=""; OTHERS=$(ls $R/visualrwkv_amd/_build/*.o)
 for SRC in "$@"; do

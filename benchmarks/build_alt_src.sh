@@ -3,7 +3,7 @@
 # time with VRWKV_HIP_LIB=...).   bash benchmarks/build_alt_src.sh <name> <source.hip> <flags...>
 set -e
 R=$(cd $(dirname $0)/.. && pwd); NAME=$1; SRC=$2; shift; shift
-python -m visualrwkv_amd.build > /dev/null
+python -c "from visualrwkv_amd import build; build.build()" > /dev/null 2>&1
 mkdir -p $R/benchmarks/_alt
 OBJ=$R/benchmarks/_alt/${SRC%.hip}_$NAME.o
 EXTRA=""; [ "$SRC" = "wkv7_capi.hip" ] && EXTRA="-fno-slp-vectorize"; [ "$SRC" = "attention.hip" ] && EXTRA="-fno-honor-nans"

@@ -243,6 +243,7 @@ DEVFN void lds_dma16_sbase(const void* uniform_base, unsigned lane_byte_off, voi
     memcpy((char*)lds_wave_base + 16 * (emu::flat_tid() & 63), (const char*)uniform_base + lane_byte_off, 16);
 }
 DEVFN char* emu_lds_from_u32(unsigned a);
+DEVFN const void* uniform_ptr(const void* ptr) { return ptr; }
 template <int IMM> DEVFN void lds_dma16_lean(const void* uniform_base, unsigned lane_byte_off, unsigned lds_dst_uniform) {
     memcpy(emu_lds_from_u32(lds_dst_uniform) + IMM + 16 * (emu::flat_tid() & 63), (const char*)uniform_base + lane_byte_off + IMM, 16);   // the immediate moves both ends
 }

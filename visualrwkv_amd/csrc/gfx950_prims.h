@@ -216,6 +216,12 @@ template <int IMM> DEVFN void lds_dma16_lean(const void* uniform_base, unsigned 
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
                  :: "v"(lane_byte_off), "s"(uniform_base), "s"(lds_dst_uniform), "n"(IMM) : "memory");
 }
+// a wave-uniform pointer the compiler keeps in VGPRs (derived next to per-lane arithmetic) -> SGPR pair, for the "s" operands above
+DEVFN const void* uniform_ptr(const void* ptr) {
+    const unsigned long long u = (unsigned long long)(uintptr_t)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
+}
 DEVFN unsigned lds_addr_u32(const void* lds_ptr) { return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_ptr); }
 // wait until at most N of this wave's vector-memory operations (loads, LDS-DMA and stores, in issue order) are outstanding
 template <int N_> DEVFN void vmem_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }

@@ -54,7 +54,8 @@ int vrwkv_wkv6_backward_bf16(int B, int T, int C, int H, const void* r, const vo
         return VRWKV_EALIGN;
     wkv6c::Bwd6Args p{T, H, (const uint16_t*)r, (const uint16_t*)k, (const uint16_t*)v, ew, (const uint16_t*)u,
                       (const uint16_t*)gy, s_ckpt, (uint16_t*)gr, (uint16_t*)gk, (uint16_t*)gv, (uint16_t*)gw, (uint16_t*)gu};
-    if (g_bwd6_variant == 1) {
+    const bool fits32 = (unsigned long long)B * T * C * 4ull < (1ull << 32);      // wkv6_bwd_v2.h forms 32-bit byte offsets (ew is fp32)
+    if (g_bwd6_variant == 1 || !fits32) {
         hipLaunchKernelGGL(wkv6c::bwd6_kernel, dim3((unsigned)((long)B * H)), dim3(256), 0, (hipStream_t)stream, p);
         return done6();
     }
