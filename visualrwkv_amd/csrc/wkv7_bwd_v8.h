@@ -26,6 +26,12 @@
 #ifndef VRWKV_V8_ROTATE
 #define VRWKV_V8_ROTATE 1
 #endif
+#ifndef VRWKV_V8_DM_FIRST
+#define VRWKV_V8_DM_FIRST 1
+#endif
+#ifndef VRWKV_V8_CHAINS
+#define VRWKV_V8_CHAINS 0
+#endif
 
 namespace wkv7v8 {
 
@@ -62,7 +68,7 @@ struct LdsV8 {
     float res[4][IMG];               // J -> P: dZt dQt dAh dKh before the decay factors, fp32 (single: flag 4 hands it back)
     float glast[2][N];               // sum_i dS_L[i][j] S_L[i][j] at the chunk's last token, by chunk parity
     unsigned flag[8];                // 0: M_qa, M_qk, M_zk written (3 per step)  1: dM written (3)  2: T written (1)  3: J operands split (4)
-                                     // 4: tail has read `res` (4)  5: P waves hold their staging pieces (4)
+                                     // 4: tail has read `res` (4)  5: P waves hold their staging pieces (4)      (flag 1: four I waves since the score-gradient pieces were re-dealt)
 };
 static_assert(sizeof(LdsV8) <= 160 * 1024, "LDS budget");
 
@@ -250,8 +256,21 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
         for (int n = 0; n < nsteps; ++n) {
             const int ci = nchunk - n, cj = ci + 1;         // this role's chunk | the J waves' chunk of this step
             WKV_STAMP(4)
-            // the seven score / score-gradient pieces go to waves 1-3: wave 0 shares its SIMD with the T chain (P wave 0).
-            //   wave 1: M_qa, dM_za   wave 2: M_qk, dM_zk, dM_qk   wave 3: M_zk, dM_qa      (12 / 12 / 10 MFMAs)
+            // the seven score / score-gradient pieces: wave 0 shares its SIMD with the T chain (P wave 0) and takes one score-gradient piece only.
+            //   wave 0: dM_za   wave 1: M_qa, dM_qk   wave 2: M_qk, dM_qa   wave 3: M_zk, dM_zk      (6 / 8 / 10 / 10 MFMAs)
+            // Score gradients of the J waves' chunk FIRST (their dR is one step old): the J waves need them in the middle of THIS step
+            // (their dM products), the scores below are for this role's own i-split.  With the scores first the J waves stood
+            // 1.2k cycles per step at flag 1 (profiles/r4_wkv7_phases_b16.json: J_dMwait) and carried the step's critical path.
+            auto score_grads = [&]() {
+                if (cj >= 0 && cj <= nchunk - 1) {
+                    const ChunkImg7& Bj = lds.b[cj % 3];
+                    const uint16_t *vi = lds.vdy[cj & 3][0], *dyi = lds.vdy[cj & 3][1], *drh = lds.dr[cj & 1][0], *drl = lds.dr[cj & 1][1];
+                    // wave 0: dM_za (6 MFMAs; it has no score piece and would stand at flag 0 meanwhile)  1: dM_qk (2)  2: dM_qa (4)  3: dM_zk (4)
+                    if (!(SKIP & 2)) dscores7(lds, Bj.sa[0], Bj.sa[1], vi, dyi, drh, drl, w == 0 ? 0 : w == 1 ? 3 : w == 2 ? 2 : 1, c16, g, la);
+                    lds_flag_add(&lds.flag[1]);
+                }
+            };
+            if (VRWKV_V8_DM_FIRST) score_grads();
             if (ci >= 0 && ci <= nchunk - 1) {
                 if (w > 0) {
                     if (!(SKIP & 2)) wkv7v6::scores6<true>(lds, lds.b[ci % 3], w, c16, g, la);
@@ -259,15 +278,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                 }
                 n_sc += 3; n_t += 1;
             }
-            if (w > 0 && cj >= 0 && cj <= nchunk - 1) {     // score gradients of the J waves' chunk (their dR is one step old)
-                const ChunkImg7& Bj = lds.b[cj % 3];
-                const uint16_t *vi = lds.vdy[cj & 3][0], *dyi = lds.vdy[cj & 3][1], *drh = lds.dr[cj & 1][0], *drl = lds.dr[cj & 1][1];
-                if (!(SKIP & 2)) {
-                    dscores7(lds, Bj.sa[0], Bj.sa[1], vi, dyi, drh, drl, w == 3 ? 2 : w - 1, c16, g, la);
-                    if (w == 2) dscores7(lds, Bj.sa[0], Bj.sa[1], vi, dyi, drh, drl, 3, c16, g, la);
-                }
-                lds_flag_add(&lds.flag[1]);
-            }
+            if (!VRWKV_V8_DM_FIRST) score_grads();
             WKV_STAMP(0)
             if (!(SKIP & 2) && ci >= 0 && ci <= nchunk - 1) {
                 const ChunkImg7& B = lds.b[ci % 3];
@@ -283,6 +294,27 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                 }
                 bf16x8 sh[2], sl[2];
                 tiles_op(dSc, sh, sl);
+                // VRWKV_V8_CHAINS: 0 = one accumulation chain per product (7 / 9 dependent MFMAs), 1 = two chains (k block 0 | k block 1), 2 = two
+                // chains with the products that need no other role's results (dS with this chunk's Ah / Kh images) issued before the
+                // waits for the score pieces and T
+                f32x4 c0 = zero4(), c1 = zero4(), v0 = zero4(), v1 = zero4();
+                auto own_products = [&]() {
+                    const bf16x8 ah0 = ld16(&B.opnd[4][la.row[0]]), ah1 = ld16(&B.opnd[4][la.row[1]]);
+                    const bf16x8 kh0 = ld16(&B.opnd[6][la.row[0]]), kh1 = ld16(&B.opnd[6][la.row[1]]);
+                    c0 = mfma32(ah0, sh[0], c0);
+                    c1 = mfma32(ah1, sh[1], c1);
+                    v0 = mfma32(sh[0], kh0, v0);
+                    v1 = mfma32(sh[1], kh1, v1);
+                    c0 = mfma32(ah0, sl[0], c0);
+                    c1 = mfma32(ah1, sl[1], c1);
+                    v0 = mfma32(sl[0], kh0, v0);
+                    v1 = mfma32(sl[1], kh1, v1);
+                    c0 = mfma32(ld16(&B.opnd[5][la.row[0]]), sh[0], c0);
+                    c1 = mfma32(ld16(&B.opnd[5][la.row[1]]), sh[1], c1);
+                    v0 = mfma32(sh[0], ld16(&B.opnd[7][la.row[0]]), v0);
+                    v1 = mfma32(sh[1], ld16(&B.opnd[7][la.row[1]]), v1);
+                };
+                if (VRWKV_V8_CHAINS == 2) own_products();
                 // the same operands, one step later, for the J waves: lane (i, g) holds columns j = 32 kb + 8g .. +7 of row i.  The J
                 // waves took their operands of the previous image at the top of this step (flag 3; J is active in steps 2 .. nchunk+1)
                 if (!(SKIP & 4) && n >= 2 && n <= nchunk + 1) lds_flag_wait(&lds.flag[3], 4u * (unsigned)(n - 1));
@@ -293,13 +325,20 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                 const uint2 dyv = lds_read_tr16(&dyi[la.trc]);                   // dY[4g+e][i]
                 const bf16x8 dyd = mk8(dyv, dyv);
                 // dSA[t][i] = sum_s M_qa[s][t] dY[s][i] + sum_j Ah[t][j] c_L[j] dS[i][j]
-                f32x4 dSA = mfma32(ld16(&lds.sc[0][la.hl]), dyd, zero4());
+                f32x4 dSA;
+                if (VRWKV_V8_CHAINS == 0) {
+                    dSA = mfma32(ld16(&lds.sc[0][la.hl]), dyd, zero4());
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    const bf16x8 ah = ld16(&B.opnd[4][la.row[kb]]);
-                    dSA = mfma32(ah, sh[kb], dSA);
-                    dSA = mfma32(ah, sl[kb], dSA);
-                    dSA = mfma32(ld16(&B.opnd[5][la.row[kb]]), sh[kb], dSA);
+                    for (int kb = 0; kb < 2; ++kb) {
+                        const bf16x8 ah = ld16(&B.opnd[4][la.row[kb]]);
+                        dSA = mfma32(ah, sh[kb], dSA);
+                        dSA = mfma32(ah, sl[kb], dSA);
+                        dSA = mfma32(ld16(&B.opnd[5][la.row[kb]]), sh[kb], dSA);
+                    }
+                } else {
+                    if (VRWKV_V8_CHAINS == 1) own_products();
+                    c0 = mfma32(ld16(&lds.sc[0][la.hl]), dyd, c0);
+                    dSA = c0 + c1;
                 }
                 uint2 xh, xl, rh, rl;
                 split4(dSA, xh, xl);
@@ -321,17 +360,25 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                 WKV_STAMP(5)
                 // dV^T[i][t] = sum_j c_L[j] dS[i][j] Kh[t][j] + sum_s dY[s][i] M_qk[s][t] + sum_s dR[s][i] M_zk[s][t]
                 {
-                    f32x4 dV = mfma32(dyd, ld16(&lds.sc[1][la.hl]), zero4());
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb) {
-                        const bf16x8 kh = ld16(&B.opnd[6][la.row[kb]]);
-                        dV = mfma32(sh[kb], kh, dV);
-                        dV = mfma32(sl[kb], kh, dV);
-                        dV = mfma32(sh[kb], ld16(&B.opnd[7][la.row[kb]]), dV);
-                    }
                     const bf16x8 rhl = mk8(rh, rl);
-                    dV = mfma32(rhl, ld16(&lds.dz[0][la.row[0]]), dV);                 // [M_zk_h M_zk_h]
-                    dV = mfma32(rhl, ld16(&lds.dz[0][la.row[1]]), dV);                 // [M_zk_l 0]
+                    f32x4 dV;
+                    if (VRWKV_V8_CHAINS == 0) {
+                        dV = mfma32(dyd, ld16(&lds.sc[1][la.hl]), zero4());
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb) {
+                            const bf16x8 kh = ld16(&B.opnd[6][la.row[kb]]);
+                            dV = mfma32(sh[kb], kh, dV);
+                            dV = mfma32(sl[kb], kh, dV);
+                            dV = mfma32(sh[kb], ld16(&B.opnd[7][la.row[kb]]), dV);
+                        }
+                        dV = mfma32(rhl, ld16(&lds.dz[0][la.row[0]]), dV);                 // [M_zk_h M_zk_h]
+                        dV = mfma32(rhl, ld16(&lds.dz[0][la.row[1]]), dV);                 // [M_zk_l 0]
+                    } else {
+                        v0 = mfma32(dyd, ld16(&lds.sc[1][la.hl]), v0);
+                        v1 = mfma32(rhl, ld16(&lds.dz[0][la.row[0]]), v1);
+                        v0 = mfma32(rhl, ld16(&lds.dz[0][la.row[1]]), v0);
+                        dV = v0 + v1;
+                    }
                     *reinterpret_cast<uint2*>(p.dv + cbase + out_off) = make_uint2(cvt_pk_bf16(dV[0], dV[1]), cvt_pk_bf16(dV[2], dV[3]));
                 }
                 WKV_STAMP(6)
@@ -378,7 +425,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
             const uint16_t* drl = lds.dr[cj & 1][1];
             const uint16_t* vi = lds.vdy[cj & 3][0];
             const uint16_t* dyi = lds.vdy[cj & 3][1];
-            n_dm += 3;
+            n_dm += 4;
             // ---------------------------------------------------------------- j-split (j = 16w + c16)
             f32x4 dZt, dQt, dAh, dKh;
             {
