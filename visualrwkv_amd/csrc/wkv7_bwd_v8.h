@@ -29,6 +29,9 @@
 #ifndef VRWKV_V8_DM_FIRST
 #define VRWKV_V8_DM_FIRST 1
 #endif
+#ifndef VRWKV_V8_SCORES_ON_J
+#define VRWKV_V8_SCORES_ON_J 0
+#endif
 #ifndef VRWKV_V8_CHAINS
 #define VRWKV_V8_CHAINS 0
 #endif
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
             };
             if (VRWKV_V8_DM_FIRST) score_grads();
             if (ci >= 0 && ci <= nchunk - 1) {
-                if (w > 0) {
+                if (w > 0 && !VRWKV_V8_SCORES_ON_J) {
                     if (!(SKIP & 2)) wkv7v6::scores6<true>(lds, lds.b[ci % 3], w, c16, g, la);
                     lds_flag_add(&lds.flag[0]);
                 }
@@ -419,6 +422,10 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
     for (int n = 0; n < nsteps; ++n) {
         const int cj = nchunk + 1 - n;
         WKV_STAMP(4)
+        if (VRWKV_V8_SCORES_ON_J && w < 3 && cj - 1 >= 0 && cj - 1 <= nchunk - 1) {      // experiment: the I waves' three score pieces on J waves 0-2
+            wkv7v6::scores6<true>(lds, lds.b[(cj - 1) % 3], w + 1, c16, g, la);
+            lds_flag_add(&lds.flag[0]);
+        }
         if (!(SKIP & 4) && cj >= 0 && cj <= nchunk - 1) {
             const ChunkImg7& B = lds.b[cj % 3];
             const uint16_t* drh = lds.dr[cj & 1][0];
