@@ -29,6 +29,18 @@
 #ifndef VRWKV_V8_DM_FIRST
 #define VRWKV_V8_DM_FIRST 1
 #endif
+#ifndef VRWKV_V8_PI
+#define VRWKV_V8_PI 0
+#endif
+#ifndef VRWKV_V8_PJ
+#define VRWKV_V8_PJ 0
+#endif
+#ifndef VRWKV_V8_PP
+#define VRWKV_V8_PP 1
+#endif
+#ifndef VRWKV_PROF_WAVE
+#define VRWKV_PROF_WAVE 0       // which wave of each role the PROF instantiation stamps (0 .. 3)
+#endif
 #ifndef VRWKV_V8_SCORES_ON_J
 #define VRWKV_V8_SCORES_ON_J 0
 #endif
@@ -136,7 +148,7 @@ DEVFN void s0_lean(LdsV8& lds, const float* s_chunk, const LeanLane& ll) {
 // TBF16: the doubling chain of T on the bf16 matrix core with split operands (2 MFMAs + 2 splits per product) or on the f32 one (4 MFMAs of
 // twice the pipe time, no VALU work)
 // PT: priority of P wave 0 while it runs the T chain (back to PP afterwards)
-template <bool PROF, int PI = 0, int PJ = 0, int PP = 1, int SKIP = 0, bool TBF16 = true, int PT = PP>
+template <bool PROF, int PI = VRWKV_V8_PI, int PJ = VRWKV_V8_PJ, int PP = VRWKV_V8_PP, int SKIP = 0, bool TBF16 = true, int PT = PP>
 __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
     LdsV8& lds = *reinterpret_cast<LdsV8*>(dyn_lds());
     const int T = p.T, H = p.H;
@@ -243,7 +255,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
 #endif
         for (; n < nchunk - 1; ++n) pstep(n, BoolTag<true>{}, q2, BoolTag<true>{});
         for (; n < nsteps; ++n) pstep(n, BoolTag<false>{}, q2, BoolTag<true>{});
-        WKV_STAMP_FLUSH(512, 10, 5)
+        WKV_STAMP_FLUSH(512 + 64 * VRWKV_PROF_WAVE, 10, 5)
         return;
     }
 
@@ -403,8 +415,8 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
             block_sync_lds();
             WKV_STAMP(3)
         }
-        WKV_STAMP_FLUSH(0, 0, 5)
-        if (PROF && blockIdx.x == 0 && tid == 0) { p.dbg[15] = realtime64_() - rt0_; p.dbg[18] = tacc_[5]; p.dbg[19] = tacc_[6]; }   // i-split: dSA + dR | dV
+        WKV_STAMP_FLUSH(64 * VRWKV_PROF_WAVE, 0, 5)
+        if (PROF && blockIdx.x == 0 && tid == 64 * VRWKV_PROF_WAVE) { p.dbg[15] = realtime64_() - rt0_; p.dbg[18] = tacc_[5]; p.dbg[19] = tacc_[6]; }   // i-split: dSA + dR | dV
         return;
     }
 
@@ -549,8 +561,8 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
         block_sync_lds();
         WKV_STAMP(3)
     }
-    WKV_STAMP_FLUSH(256, 5, 5)
-    if (PROF && blockIdx.x == 0 && tid == 256) { p.dbg[16] = tacc_[5]; p.dbg[17] = tacc_[6]; }   // j-split: operand reads + split | outputs
+    WKV_STAMP_FLUSH(256 + 64 * VRWKV_PROF_WAVE, 5, 5)
+    if (PROF && blockIdx.x == 0 && tid == 256 + 64 * VRWKV_PROF_WAVE) { p.dbg[16] = tacc_[5]; p.dbg[17] = tacc_[6]; }   // j-split: operand reads + split | outputs
 }
 
 }  // namespace wkv7v8
