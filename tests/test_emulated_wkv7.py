@@ -57,7 +57,8 @@ def test_forward_from_state(emu_lib):
     assert rel_rms(y2.double(), y_ref0) < 4e-3
 
 
-@pytest.mark.parametrize("mode,T", [(6, 48), (7, 16), (7, 32), (7, 96), (8, 16), (8, 32), (8, 48), (8, 64), (8, 80), (8, 160), (9, 16), (9, 32), (9, 48), (9, 64), (9, 80), (9, 160)])
+@pytest.mark.parametrize("mode,T", [(6, 48), (7, 16), (7, 32), (7, 96), (8, 16), (8, 32), (8, 48), (8, 64), (8, 80), (8, 160), (9, 16), (9, 32), (9, 48), (9, 64), (9, 80), (9, 160),
+                                    (10, 16), (10, 32), (10, 48), (10, 64), (10, 80), (10, 160)])
 def test_backward_chunked(emu_lib, mode, T):
     """Chunked MFMA backward kernels run lane-exactly on the host: 6 = the producer / consumer schedule (wkv7_bwd_v5.h), 7 = the three-stage wave pipeline (wkv7_bwd_v6.h;
     1, 2 and 6 chunks: pipeline shorter than, equal to and longer than its depth), 8 = the same pipeline with the full-row memory

@@ -148,7 +148,11 @@ DEVFN void s0_lean(LdsV8& lds, const float* s_chunk, const LeanLane& ll) {
 // TBF16: the doubling chain of T on the bf16 matrix core with split operands (2 MFMAs + 2 splits per product) or on the f32 one (4 MFMAs of
 // twice the pipe time, no VALU work)
 // PT: priority of P wave 0 while it runs the T chain (back to PP afterwards)
-template <bool PROF, int PI = VRWKV_V8_PI, int PJ = VRWKV_V8_PJ, int PP = VRWKV_V8_PP, int SKIP = 0, bool TBF16 = true, int PT = PP>
+// AHEAD: the three score pieces (M_qa, M_qk, M_zk) of a chunk are formed by P waves 1-3 at the END of the step in which the chunk's
+// images are built -- where those waves stood ~1.9k cycles at the barrier (profiles/r4b_wkv7_phases_waves_v8.jsonl) -- instead of by I
+// waves 1-3 at the start of the next step, where they delayed the i-split's chain by 1.6-1.8k cycles.  The P waves prepare the
+// images BEFORE their tail for that (the queue entry of the prepare is assigned after the tail has consumed the old one).
+template <bool PROF, int PI = VRWKV_V8_PI, int PJ = VRWKV_V8_PJ, int PP = VRWKV_V8_PP, int SKIP = 0, bool TBF16 = true, int PT = PP, bool AHEAD = false>
 __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
     LdsV8& lds = *reinterpret_cast<LdsV8*>(dyn_lds());
     const int T = p.T, H = p.H;
@@ -209,6 +213,8 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                     if (w == 1) rows_lean<0>(lds, p, cp - 1, cb16, ll); else if (w == 2) rows_lean<1>(lds, p, cp - 1, cb16, ll);
                     else if (w == 3) rows_lean<2>(lds, p, cp - 1, cb16, ll);
                 } else if (w > 0 && cp >= 1) dma_chunk<LdsV8, 3>(lds, p, head_base + (size_t)(cp - 1) * L * ts, cp - 1, w - 1, ts, dl);
+                Decay dd{};
+                if (AHEAD && w > 0 && do_prep) { dd = prep7(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la); lds_flag_add(&lds.flag[6]); }
                 // T = (I - M_za)^-1 of the I waves' chunk, from the images this role built a step ago: the doubling chain is 28
                 // dependent MFMA / split stages and nobody needs T before the I waves have formed dSA
                 if (w == 0 && (FULL || (cd >= 0 && cd <= nchunk - 1))) {
@@ -217,6 +223,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                     lds_flag_add(&lds.flag[2]);
                     if (PT != PP) wave_priority<PP>();
                 }
+                if (AHEAD && w == 0 && do_prep) { dd = prep7(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la); lds_flag_add(&lds.flag[6]); }
                 // the J waves have lifted S0 and their dS operands into registers (and split them: VALU only, like the tail, which
                 // therefore runs beside their matrix-core phase); J is active in steps 2 .. nchunk + 1 and counts 4 per step
                 if (!(SKIP & 4) && (FULL || (n >= 2 && n <= nchunk + 1))) lds_flag_wait(&lds.flag[3], 4u * (unsigned)(n - 1));
@@ -233,9 +240,16 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                 if (SHIFT) { q2 = q1; q1 = q0; }
                 TailRaw& qn = SHIFT ? q0 : qt;
                 if (do_prep) {
-                    const Decay dd = prep7(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la);
+                    if (!AHEAD) dd = prep7(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la);
                     qn.q = raw.q; qn.k = raw.k; qn.z = raw.z; qn.a = raw.a;
                     qn.x2[0] = dd.x2[0]; qn.x2[1] = dd.x2[1]; qn.x2[2] = dd.x2[2]; qn.x2[3] = dd.x2[3];
+                }
+                if (AHEAD && w > 0 && do_prep) {
+                    // scores of chunk cp for the I waves' next step: all four P waves' images are written (flag 6), and the I waves are
+                    // past the last use of the previous scores (flag 0: four per step in which they are active, steps 1 ..)
+                    lds_flag_wait(&lds.flag[6], 4u * (unsigned)(n + 1));
+                    if (n >= 1) lds_flag_wait(&lds.flag[0], 4u * (unsigned)n);
+                    wkv7v6::scores6<true>(lds, lds.b[cp % 3], w, c16, g, la);
                 }
                 WKV_STAMP(1)
                 if (FULL) vmem_wait<5>(); else vmem_drain();
@@ -287,7 +301,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
             };
             if (VRWKV_V8_DM_FIRST) score_grads();
             if (ci >= 0 && ci <= nchunk - 1) {
-                if (w > 0 && !VRWKV_V8_SCORES_ON_J) {
+                if (w > 0 && !VRWKV_V8_SCORES_ON_J && !AHEAD) {
                     if (!(SKIP & 2)) wkv7v6::scores6<true>(lds, lds.b[ci % 3], w, c16, g, la);
                     lds_flag_add(&lds.flag[0]);
                 }
@@ -335,7 +349,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                 if (!(SKIP & 4) && n >= 2 && n <= nchunk + 1) lds_flag_wait(&lds.flag[3], 4u * (unsigned)(n - 1));
                 *reinterpret_cast<bf16x8*>(&lds.dsi[0][img_row]) = sh[0]; *reinterpret_cast<bf16x8*>(&lds.dsi[0][img_row1]) = sh[1];
                 *reinterpret_cast<bf16x8*>(&lds.dsi[1][img_row]) = sl[0]; *reinterpret_cast<bf16x8*>(&lds.dsi[1][img_row1]) = sl[1];
-                lds_flag_wait(&lds.flag[0], n_sc);
+                if (!AHEAD) lds_flag_wait(&lds.flag[0], n_sc);
                 WKV_STAMP(1)
                 const uint2 dyv = lds_read_tr16(&dyi[la.trc]);                   // dY[4g+e][i]
                 const bf16x8 dyd = mk8(dyv, dyv);
@@ -396,6 +410,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                     }
                     *reinterpret_cast<uint2*>(p.dv + cbase + out_off) = make_uint2(cvt_pk_bf16(dV[0], dV[1]), cvt_pk_bf16(dV[2], dV[3]));
                 }
+                if (AHEAD) lds_flag_add(&lds.flag[0]);            // (waits for the reads) the scores of this chunk are consumed
                 WKV_STAMP(6)
                 // dS^T <- diag(c_L) dS^T + [Qt^T | Zt^T] [dY ; dR]
                 const bf16x8 y1 = mk8(dyv, rh), y2 = mk8(0u, 0u, rl.x, rl.y);

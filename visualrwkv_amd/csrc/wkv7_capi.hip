@@ -11,6 +11,9 @@
 #include <wkv7_bwd_v6.h>
 #include <wkv7_bwd_v7.h>
 #include <wkv7_bwd_v8.h>
+#ifndef VRWKV_PROF_AHEAD
+#define VRWKV_PROF_AHEAD false      // the profile entry point stamps the default schedule; -DVRWKV_PROF_AHEAD=true: variant 9's
+#endif
 
 namespace {
 
@@ -68,7 +71,7 @@ int vrwkv_wkv7_set_forward_variant(int variant) {
 }
 
 int vrwkv_wkv7_set_backward_variant(int variant) {
-    if (variant != -1 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && !(variant >= 60 && variant < 90)) return VRWKV_EINVAL;   // see include/visualrwkv_hip.h
+    if (variant != -1 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9 && !(variant >= 60 && variant < 90)) return VRWKV_EINVAL;   // see include/visualrwkv_hip.h
     g_bwd_variant = variant;
     return VRWKV_OK;
 }
@@ -148,10 +151,11 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H, const void* w, const void* q, 
     const dim3 grid((unsigned)((long)B * H));
     int var = g_bwd_variant == -1 ? BWD_DEFAULT : g_bwd_variant;
     const bool fits32 = (unsigned long long)B * T * H * 64ull * 4ull < (1ull << 32);      // wkv7_bwd_v8.h uses 32-bit byte offsets inside a tensor
-    if (!fits32 && (var == 8 || var >= 80)) var = 6;
-    if (var == 8 || (var >= 80 && var < 90)) {
+    if (!fits32 && (var == 8 || var == 9 || var >= 80)) var = 6;
+    if (var == 8 || var == 9 || (var >= 80 && var < 90)) {
         // one copy of dL/dS, T chain on P wave 0, full-row memory role, 12 waves (wkv7_bwd_v8.h)
         void (*kern)(wkv7::BwdArgs) = &wkv7v8::bwd_kernel_v8<false>;
+        if (var == 9) kern = &wkv7v8::bwd_kernel_v8<false, VRWKV_V8_PI, VRWKV_V8_PJ, VRWKV_V8_PP, 0, true, VRWKV_V8_PP, true>;      // score pieces a step ahead on the P waves
 #ifdef VRWKV_V6_EXPERIMENTS   // role-timing builds: one or two roles switched off, results garbage
         switch (g_bwd_variant) {
             case 81: kern = &wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 1>; break;     // no P
@@ -291,10 +295,10 @@ int vrwkv_wkv7_profile_bf16(int backward, int B, int T, int H, const void* w, co
         wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                         (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
                         (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da, dbg};
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7v8::bwd_kernel_v8<true>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wkv7v8::bwd_kernel_v8<true, VRWKV_V8_PI, VRWKV_V8_PJ, VRWKV_V8_PP, 0, true, VRWKV_V8_PP, VRWKV_PROF_AHEAD>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7v8::LdsV8));
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((wkv7v8::bwd_kernel_v8<true>), grid, dim3(768), sizeof(wkv7v8::LdsV8), st, p);
+        hipLaunchKernelGGL((wkv7v8::bwd_kernel_v8<true, VRWKV_V8_PI, VRWKV_V8_PJ, VRWKV_V8_PP, 0, true, VRWKV_V8_PP, VRWKV_PROF_AHEAD>), grid, dim3(768), sizeof(wkv7v8::LdsV8), st, p);
     } else if (backward == 3) {                     // three-stage pipeline with the full-row memory role (wkv7_bwd_v7.h): same stamps as v6
         wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                         (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
