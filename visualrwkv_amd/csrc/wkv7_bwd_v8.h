@@ -142,6 +142,69 @@ DEVFN void s0_lean(LdsV8& lds, const float* s_chunk, const LeanLane& ll) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ tail with the prepare's decay factors
+// VRWKV_V8_TAILQ: the queue entry of a chunk also carries c_t and 1 / c_t (8 more registers per entry, three entries) so that the tail,
+// three steps later, does not form them again (8 v_exp_f32 -- quarter rate -- and their DPP moves per lane and step)
+#ifndef VRWKV_V8_TAILQ
+#define VRWKV_V8_TAILQ 0
+#endif
+struct TailQ { uint2 q, k, z, a; float x2[4]; float cc[VRWKV_V8_TAILQ ? 4 : 1], ic[VRWKV_V8_TAILQ ? 4 : 1]; };
+struct Prep8 { float x2[4], cc[4], ic[4]; };
+DEVFN Prep8 prep8(ChunkImg7& B, const RawP& raw, int c16, int j0, const LaneAddr& la) {
+    float q[4], k[4], z[4], a[4];
+    unpack4(raw.q, q); unpack4(raw.k, k); unpack4(raw.z, z); unpack4(raw.a, a);
+    const Decay d = decay_scan(raw.w);
+    Prep8 o;
+    float zt[4], qt[4], ah[4], kh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float cc = fast_exp2(d.x2[e]), ic = fast_exp2(-d.x2[e]);
+        const float cp = dpp_shr1_fill(cc, 1.f);
+        zt[e] = z[e] * cp; qt[e] = q[e] * cc; ah[e] = a[e] * ic; kh[e] = k[e] * ic;
+        o.x2[e] = d.x2[e]; o.cc[e] = cc; o.ic[e] = ic;
+    }
+    uint2 hh, ll;
+    split4(zt, hh, ll); st8(&B.opnd[0][la.own], hh); st8(&B.opnd[1][la.own], ll);
+    split4(qt, hh, ll); st8(&B.opnd[2][la.own], hh); st8(&B.opnd[3][la.own], ll);
+    split4(ah, hh, ll); st8(&B.opnd[4][la.own], hh); st8(&B.opnd[5][la.own], ll);
+    split4(kh, hh, ll); st8(&B.opnd[6][la.own], hh); st8(&B.opnd[7][la.own], ll);
+    const float sav[4] = {raw.sa.x, raw.sa.y, raw.sa.z, raw.sa.w};
+    split4(sav, hh, ll); st8(&B.sa[0][la.own], hh); st8(&B.sa[1][la.own], ll);
+    if (c16 == 15) *reinterpret_cast<float4*>(&B.cl[j0]) = make_float4(o.cc[0], o.cc[1], o.cc[2], o.cc[3]);
+    return o;
+}
+DEVFN void tail8(LdsV8& lds, int par, const TailQ& tr, const BwdArgs& p, size_t u, unsigned lane_boff, int c16, int pw, int g, const LaneAddr& la) {
+    const float4 zt4 = *reinterpret_cast<const float4*>(&lds.res[0][la.f32]);
+    const float4 qt4 = *reinterpret_cast<const float4*>(&lds.res[1][la.f32]);
+    const float4 ah4 = *reinterpret_cast<const float4*>(&lds.res[2][la.f32]);
+    const float4 kh4 = *reinterpret_cast<const float4*>(&lds.res[3][la.f32]);
+    const float4 gl4 = *reinterpret_cast<const float4*>(&lds.glast[par][16 * pw + 4 * g]);
+    lds_flag_add(&lds.flag[4]);                           // (waits for the reads above) the J waves may overwrite `res`
+    const float dZt[4] = {zt4.x, zt4.y, zt4.z, zt4.w}, dQt[4] = {qt4.x, qt4.y, qt4.z, qt4.w};
+    const float dAh[4] = {ah4.x, ah4.y, ah4.z, ah4.w}, dKh[4] = {kh4.x, kh4.y, kh4.z, kh4.w};
+    const float glv[4] = {gl4.x, gl4.y, gl4.z, gl4.w};
+    float q[4], k[4], z[4], a[4];
+    unpack4(tr.q, q); unpack4(tr.k, k); unpack4(tr.z, z); unpack4(tr.a, a);
+    float dz[4], dq[4], da[4], dk[4], dw[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x2 = tr.x2[e], l2 = x2 - dpp_shr1_fill(x2, 0.f);      // log2 c_t from the queue; log2 w_t = its difference along t
+        const float cc = VRWKV_V8_TAILQ ? tr.cc[VRWKV_V8_TAILQ ? e : 0] : fast_exp2(x2), ic = VRWKV_V8_TAILQ ? tr.ic[VRWKV_V8_TAILQ ? e : 0] : fast_exp2(-x2);
+        const float cp = dpp_shr1_fill(cc, 1.f);
+        dz[e] = dZt[e] * cp; dq[e] = dQt[e] * cc; da[e] = dAh[e] * ic; dk[e] = dKh[e] * ic;
+        float gt = dq[e] * q[e] - da[e] * a[e] - dk[e] * k[e] + dpp_shl<1>(dz[e] * z[e]);
+        if (c16 == 15) gt += glv[e];
+        gt += dpp_shl<1>(gt); gt += dpp_shl<2>(gt); gt += dpp_shl<4>(gt); gt += dpp_shl<8>(gt);   // suffix sum over t
+        dw[e] = gt * (l2 * LN2);
+    }
+    auto out = [&](uint16_t* base) { return reinterpret_cast<uint2*>(reinterpret_cast<char*>(base + u) + lane_boff); };   // uniform base + lane offset
+    *out(p.dw) = make_uint2(cvt_pk_bf16(dw[0], dw[1]), cvt_pk_bf16(dw[2], dw[3]));
+    *out(p.dq) = make_uint2(cvt_pk_bf16(dq[0], dq[1]), cvt_pk_bf16(dq[2], dq[3]));
+    *out(p.dk) = make_uint2(cvt_pk_bf16(dk[0], dk[1]), cvt_pk_bf16(dk[2], dk[3]));
+    *out(p.dz) = make_uint2(cvt_pk_bf16(dz[0], dz[1]), cvt_pk_bf16(dz[2], dz[3]));
+    *out(p.da) = make_uint2(cvt_pk_bf16(da[0], da[1]), cvt_pk_bf16(da[2], da[3]));
+}
+
 // ------------------------------------------------------------------------------------------ kernel
 // dbg (PROF): as wkv7_bwd_v6.h.  SKIP (timing experiments only, results are garbage): bit 0 P does nothing, bit 1 I only raises
 // its flags, bit 2 J does nothing.
@@ -182,7 +245,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
     if (role == 2) {
         // ================================================================== P: images of chunk cp, T of chunk cp + 1, tail of chunk cp + 3
         wave_priority<PP>();
-        TailRaw q0{}, q1{}, q2{};                           // inputs of chunks cp+1, cp+2, cp+3 at the top of a step
+        TailQ q0{}, q1{}, q2{};                             // inputs of chunks cp+1, cp+2, cp+3 at the top of a step
         const unsigned lane_boff = out_off * 2u;
         const DmaLane dl = dma_lane(lane, ts);
         const LeanLane ll = lean_lane(lane, w > 0 ? w - 1 : 0, ts);
@@ -193,7 +256,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
         // qt: the queue entry the tail consumes.  With SHIFT the three entries move up by one afterwards (q2 <- q1 <- q0 <- new);
         // without, the new entry replaces the consumed one in place and the CALLER rotates the names (steady state, in threes:
         // the 24 register moves of the shift are a twentieth of this role's instructions)
-        auto pstep = [&](int n, auto full_tag, TailRaw& qt, auto shift_tag) {
+        auto pstep = [&](int n, auto full_tag, TailQ& qt, auto shift_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
             constexpr bool SHIFT = decltype(shift_tag)::value;
             const int cp = nchunk - 1 - n, cd = cp + 1, ct = cp + 3;      // images | the I waves' chunk: T now, S0 for the J waves' next step | tail
@@ -213,8 +276,8 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                     if (w == 1) rows_lean<0>(lds, p, cp - 1, cb16, ll); else if (w == 2) rows_lean<1>(lds, p, cp - 1, cb16, ll);
                     else if (w == 3) rows_lean<2>(lds, p, cp - 1, cb16, ll);
                 } else if (w > 0 && cp >= 1) dma_chunk<LdsV8, 3>(lds, p, head_base + (size_t)(cp - 1) * L * ts, cp - 1, w - 1, ts, dl);
-                Decay dd{};
-                if (AHEAD && w > 0 && do_prep) { dd = prep7(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la); lds_flag_add(&lds.flag[6]); }
+                Prep8 dd{};
+                if (AHEAD && w > 0 && do_prep) { dd = prep8(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la); lds_flag_add(&lds.flag[6]); }
                 // T = (I - M_za)^-1 of the I waves' chunk, from the images this role built a step ago: the doubling chain is 28
                 // dependent MFMA / split stages and nobody needs T before the I waves have formed dSA
                 if (w == 0 && (FULL || (cd >= 0 && cd <= nchunk - 1))) {
@@ -223,7 +286,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                     lds_flag_add(&lds.flag[2]);
                     if (PT != PP) wave_priority<PP>();
                 }
-                if (AHEAD && w == 0 && do_prep) { dd = prep7(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la); lds_flag_add(&lds.flag[6]); }
+                if (AHEAD && w == 0 && do_prep) { dd = prep8(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la); lds_flag_add(&lds.flag[6]); }
                 // the J waves have lifted S0 and their dS operands into registers (and split them: VALU only, like the tail, which
                 // therefore runs beside their matrix-core phase); J is active in steps 2 .. nchunk + 1 and counts 4 per step
                 if (!(SKIP & 4) && (FULL || (n >= 2 && n <= nchunk + 1))) lds_flag_wait(&lds.flag[3], 4u * (unsigned)(n - 1));
@@ -235,14 +298,18 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                         if (w == 1) s0_lean<0>(lds, sc, ll); else if (w == 2) s0_lean<1>(lds, sc, ll); else if (w == 3) s0_lean<2>(lds, sc, ll);
                     } else if (cd >= 0 && cd <= nchunk - 1) dma_state(lds.s0, cd > 0 ? sbase + (size_t)(cd - 1) * N * N : nullptr, k0, k1, lane);
                 }
-                if (FULL || (ct >= 0 && ct <= nchunk - 1)) tail7(lds, ct & 1, qt, p, head_base + (size_t)ct * L * ts, lane_boff, c16, w, g, la);
+                if (FULL || (ct >= 0 && ct <= nchunk - 1)) tail8(lds, ct & 1, qt, p, head_base + (size_t)ct * L * ts, lane_boff, c16, w, g, la);
                 WKV_STAMP(0)
                 if (SHIFT) { q2 = q1; q1 = q0; }
-                TailRaw& qn = SHIFT ? q0 : qt;
+                TailQ& qn = SHIFT ? q0 : qt;
                 if (do_prep) {
-                    if (!AHEAD) dd = prep7(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la);
+                    if (!AHEAD) dd = prep8(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la);
                     qn.q = raw.q; qn.k = raw.k; qn.z = raw.z; qn.a = raw.a;
                     qn.x2[0] = dd.x2[0]; qn.x2[1] = dd.x2[1]; qn.x2[2] = dd.x2[2]; qn.x2[3] = dd.x2[3];
+                    if (VRWKV_V8_TAILQ) {
+#pragma unroll
+                        for (int e = 0; e < (VRWKV_V8_TAILQ ? 4 : 1); ++e) { qn.cc[e] = dd.cc[e]; qn.ic[e] = dd.ic[e]; }
+                    }
                 }
                 if (AHEAD && w > 0 && do_prep) {
                     // scores of chunk cp for the I waves' next step: all four P waves' images are written (flag 6), and the I waves are
