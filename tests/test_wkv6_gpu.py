@@ -47,6 +47,27 @@ def test_op_matches_oracle(B, T, H):
     assert rel_rms(gu.double(), g_ref[4]) < 1e-2                               # per-sample bf16 rows summed in bf16, as the reference (model.py:84)
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+def test_backward_kernel_generations_against_oracle(variant):
+    """Both backward kernels behind vrwkv_wkv6_backward_bf16 -- 1: four waves (wkv6_chunked.h), 2: three-role pipeline of twelve
+    (wkv6_bwd_v2.h, the default) -- on a ragged length that crosses the rings of the pipeline (T = 133: nine chunks, the last of 5 tokens)."""
+    from visualrwkv_amd import hip_lib
+    lib = hip_lib.load()
+    B, T, H = 2, 133, 3
+    r, k, v, w, u, gy = make_inputs6(B, T, H, seed=4242)
+    try:
+        assert lib.vrwkv_wkv6_set_backward_variant(variant) == 0
+        y, (gr, gk, gv, gw, gu) = _run(r, k, v, w, u, gy)
+    finally:
+        assert lib.vrwkv_wkv6_set_backward_variant(-1) == 0
+    assert lib.vrwkv_wkv6_set_backward_variant(3) != 0                             # unknown generation: refused
+    y_ref, g_ref = wkv6_autograd(r, k, v, w, u, gy)
+    C = H * 64
+    for a, ref, n in zip((gr, gk, gv, gw), g_ref[:4], "rkvw"):
+        bf16_close(a, ref.reshape(B, T, C), f"wkv6 g{n} variant {variant}", max_flip=0.10 if n == "w" else 0.02)
+    assert rel_rms(gu.double(), g_ref[4]) < 1e-2
+
+
 def test_strong_decays_stay_finite():
     """Per-token log decays down to -e^2.3 = -10: the midpoint-referenced exponents stay in range."""
     r, k, v, w, u, gy = make_inputs6(1, 64, 2, seed=3, w_lo=-2.0, w_hi=2.3)
