@@ -306,10 +306,28 @@ class SamImageEncoder(nn.Module):
         else:
             for blk in self.blocks:
                 x = blk(x)
-        x = self.neck(x.permute(0, 3, 1, 2))
-        B, C, H, W = x.shape                        # space-to-depth: each 2x2 block -> 4C channels
-        x = x.view(B, C, H // 2, 2, W // 2, 2).permute(0, 2, 4, 1, 3, 5).reshape(B, H // 2, W // 2, C * 4)
+        x = self.neck_nhwc(x)                       # (B, H, W, C)
+        B, H, W, C = x.shape                        # space-to-depth: each 2x2 block -> 4C channels, channel index (c, dh, dw)
+        x = x.view(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 5, 2, 4).reshape(B, H // 2, W // 2, C * 4)
         return x.permute(0, 3, 1, 2)
+
+    def neck_nhwc(self, x):
+        """The neck of src/sam.py:149-165 (conv 1x1, LayerNorm2d, conv 3x3 pad 1, LayerNorm2d) on the channels-last activations the
+        blocks produce, as two GEMMs: a 1x1 convolution is a Linear over the channel axis, the 3x3 one a Linear over the nine
+        shifted copies of the zero-padded map (weight re-ordered to (out, kh, kw, in)).  Handing MIOpen the (B, C, H, W) VIEW of
+        this tensor made it run its find step on the first call with `naive_conv_ab_nonpacked_fwd_nhwc_*_double_*` as the reference
+        (25.6 ms per call, 16 calls in the warm-up: profiles/r4b_cfg5_kernel_stats_head.csv); the timed steps are unchanged (CK's
+        grouped-conv kernel took 0.68 ms per call).  Same modules and state-dict keys; `self.neck(x_nchw)` stays valid."""
+        c1, n1, c3, n2 = self.neck
+        B, H, W, C = x.shape
+        y = F.linear(x, c1.weight.view(c1.weight.shape[0], C))
+        y = F.layer_norm(y, (y.shape[-1],), n1.weight, n1.bias, n1.eps)
+        Co = y.shape[-1]
+        yp = F.pad(y, (0, 0, 1, 1, 1, 1))           # zero border on W and H
+        cols = torch.cat([yp[:, kh:kh + H, kw:kw + W, :] for kh in range(3) for kw in range(3)], dim=-1)      # (B, H, W, 9 Co), (kh, kw, in) order
+        w3 = c3.weight.permute(0, 2, 3, 1).reshape(c3.weight.shape[0], 9 * Co)
+        z = F.linear(cols, w3)
+        return F.layer_norm(z, (z.shape[-1],), n2.weight, n2.bias, n2.eps)
 
 
 # ------------------------------------------------------------------------------------------------
