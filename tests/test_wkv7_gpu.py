@@ -66,7 +66,7 @@ def test_forward_parity(hip_lib, dev, B, T, H, variant):
     assert rel_rms(sa.cpu(), sar) < 2e-5
 
 
-@pytest.mark.parametrize("variant", [5, 6, 7, 8])          # 7: wkv7_bwd_v7.h (full-row memory role); wkv7_bwd_v5.h (8 waves; also the sequence-parallel kernel), wkv7_bwd_v6.h (12-wave pipeline, default)
+@pytest.mark.parametrize("variant", [5, 6, 7, 8, 9])       # 9: the default (v8 + score pieces a step ahead); 8: wkv7_bwd_v8.h; 7: wkv7_bwd_v7.h (full-row memory role); wkv7_bwd_v5.h (8 waves; also the sequence-parallel kernel), wkv7_bwd_v6.h (12-wave pipeline, default)
 @pytest.mark.parametrize("B,T,H", [(1, 16, 1), (2, 64, 3), (1, 384, 12), (3, 208, 5)])
 def test_backward_parity(hip_lib, dev, B, T, H, variant):
     w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=B * 77 + T + H)

@@ -33,7 +33,7 @@ constexpr long FWD_ISPLIT_MAX_HEADS = 128;
 constexpr bool FWD_DEFAULT_V4 = true;      // wkv7_fwd_v4.h (full-row memory traffic) for B*H > 128
 // same-box A/B on MI355X, B=16 x 2624 x 32 heads: micro-benchmark (random inputs) 1.042 -> 0.993 ms, inside the training step
 // (bench.py, VRWKV_BWD_VARIANT=5 / 6) 0.981 -> 0.872 ms
-constexpr int BWD_DEFAULT = 8;          // 5: wkv7_bwd_v5.h   6: wkv7_bwd_v6.h   7: wkv7_bwd_v7.h   8: wkv7_bwd_v8.h (one dS copy, T on P wave 0, full-row LDS-DMA)
+constexpr int BWD_DEFAULT = 9;          // 5: wkv7_bwd_v5.h   6: wkv7_bwd_v6.h   7: wkv7_bwd_v7.h   8: wkv7_bwd_v8.h (one dS copy, T on P wave 0, full-row LDS-DMA)   9: 8 with the score pieces a step ahead on the P waves
 
 inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 
