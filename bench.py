@@ -401,7 +401,7 @@ def main():
             ms = sum(x for x, _ in kinds["bwd"]) / len(kinds["bwd"])
             elems = kinds["bwd"][0][1]
             ach = elems * BWD_B / ms / 1e6
-            out["roofline"] = {"bound": "hbm", "kernel": {"5": "wkv7v5::bwd_kernel_v5", "6": "wkv7v6::bwd_kernel_v6", "7": "wkv7v7::bwd_kernel_v7", "8": "wkv7v8::bwd_kernel_v8"}.get(os.environ.get("VRWKV_BWD_VARIANT", ""), "wkv7v8::bwd_kernel_v8<AHEAD>"), "achieved": ach, "peak": HBM_PEAK_GBPS,
+            out["roofline"] = {"bound": "hbm", "kernel": {"5": "wkv7v5::bwd_kernel_v5", "6": "wkv7v6::bwd_kernel_v6", "7": "wkv7v7::bwd_kernel_v7", "8": "wkv7v8::bwd_kernel_v8"}.get(os.environ.get("VRWKV_BWD_VARIANT", ""), "wkv7v8::bwd_kernel_v8<AHEAD>" if a.micro_bsz * MODELS[a.model]["n_embd"] // 64 > 256 else "wkv7v8::bwd_kernel_v8"), "achieved": ach, "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
                                "avg_ms": ms, "launches": len(kinds["bwd"]), "algorithmic_bytes": elems * BWD_B}
             if "fwd" in kinds:

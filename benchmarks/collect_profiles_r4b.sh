@@ -13,7 +13,7 @@ cd /tmp; export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $O/step_pmc -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-grad-cp-companion --fast-init > $O/step_pmc.log 2>&1
 cd $R
 python benchmarks/mfma_util.py $O/step_pmc > $O/step_mfma_util.json 2>&1; rm -rf $O/step_pmc
-python benchmarks/wkv7_ab.py --B 8 16 --fwd 4 -1 --bwd 5 6 7 8 --rounds 4 2>&1 | grep -v amdgpu > $O/wkv7_ab.jsonl
+python benchmarks/wkv7_ab.py --B 8 16 --fwd 4 -1 --bwd 5 6 7 8 9 --rounds 4 2>&1 | grep -v amdgpu > $O/wkv7_ab.jsonl
 python benchmarks/wkv7_micro.py --B 8 16 32 --iters 20 2>&1 | grep -v amdgpu > $O/wkv7_micro.jsonl
 for v in 1 2; do VRWKV_WKV6_BWD_VARIANT=$v python benchmarks/wkv6_micro.py 2 4 8 16 2>&1 | grep '^{' | sed "s/^{/{\"bwd_variant\": $v, /"; done > $O/wkv6_micro.jsonl
 python benchmarks/eltwise_micro.py 16 2>&1 | grep '^{' > $O/eltwise_micro.json

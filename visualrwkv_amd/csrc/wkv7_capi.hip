@@ -149,7 +149,9 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H, const void* w, const void* q, 
                     (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)((long)B * H));
-    int var = g_bwd_variant == -1 ? BWD_DEFAULT : g_bwd_variant;
+    // default: variant 9 when the launch has more workgroups than the chip has CUs (measured -0.4 ... -2.3 % at B x H = 384 ... 1024), variant 8
+    // for a single round of workgroups (B x H <= 256: 9 measured +0.3 ... +1.8 % there); profiles/r4_wkv7_ab.jsonl, r4c_wkv7_ab.jsonl
+    int var = g_bwd_variant == -1 ? ((long)B * H > 256 ? BWD_DEFAULT : 8) : g_bwd_variant;
     const bool fits32 = (unsigned long long)B * T * H * 64ull * 4ull < (1ull << 32);      // wkv7_bwd_v8.h uses 32-bit byte offsets inside a tensor
     if (!fits32 && (var == 8 || var == 9 || var >= 80)) var = 6;
     if (var == 8 || var == 9 || (var >= 80 && var < 90)) {
