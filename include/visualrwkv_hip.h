@@ -198,6 +198,10 @@ int vrwkv_wkv7_step_bf16(int B, int H, const void* w, const void* q, const void*
  *            schedule of 8 waves (csrc/wkv7_bwd_v5.h; also the sequence-parallel kernel).  Anything else: VRWKV_EINVAL. */
 int vrwkv_wkv7_set_forward_variant(int variant);
 int vrwkv_wkv7_set_backward_variant(int variant);
+/* The kernel generation the LAST vrwkv_wkv7_forward_bf16 (backward == 0) / vrwkv_wkv7_backward_bf16 (backward != 0) launch of this
+ * process resolved to, in the numbering above (forward: 7 = wkv7_fwd_v4.h, 6 = two workgroups per head, 4 = wkv7_fwd_v3.h; 0 = none yet):
+ * lets a parity test assert WHICH kernel the default dispatch chose for its shape. */
+int vrwkv_wkv7_last_variant(int backward);
 
 /* ---- Fused element-wise glue of RWKV_Tmix_x070 / RWKV_CMix_x070 (VisualRWKV-v7/v7.00/src/model.py), forward and
  * backward.  Activations are (ntok, C) bf16 contiguous (ntok = B*T), parameters C bf16.  Parameter gradients

@@ -49,6 +49,8 @@ int emu_wkv7_backward_chunked(int B, int T, int H, const void* w, const void* q,
     if (mode == 8) { emu::launch(grid, dim3(768), [&] { wkv7v7::bwd_kernel_v7<false>(p); }); return (int)sizeof(wkv7v7::LdsV7); }   // + full-row memory role
     if (mode == 9) { emu::launch(grid, dim3(768), [&] { wkv7v8::bwd_kernel_v8<false>(p); }); return (int)sizeof(wkv7v8::LdsV8); }   // one copy of dS, T on P wave 0
     if (mode == 10) { emu::launch(grid, dim3(768), [&] { wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, true>(p); }); return (int)sizeof(wkv7v8::LdsV8); }   // + score pieces a step ahead on the P waves
+    if (mode == 11) { emu::launch(grid, dim3(768), [&] { wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, false, true>(p); }); return (int)sizeof(wkv7v8::LdsV8); }  // tail on the J waves
+    if (mode == 12) { emu::launch(grid, dim3(768), [&] { wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, true, true>(p); }); return (int)sizeof(wkv7v8::LdsV8); }   // + score pieces a step ahead
     return -1;
 }
 

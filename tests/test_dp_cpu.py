@@ -47,6 +47,27 @@ def test_single_process_matches_torch_adamw():
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
 
 
+def test_a_closed_engine_no_longer_drives_the_model():
+    """close() removes the engine's autograd / forward hooks: a model that gets a NEW engine must not keep feeding
+    the old one's flat buffer on every backward."""
+    from visualrwkv_amd.dp import Zero1Engine
+    m = _model()
+    x, y = _data()
+    old = Zero1Engine(m, lr=1e-2, bucket_mb=0.001)
+    old.zero_grad(); _loss(m, x, y).backward(); old.step()
+    old.close()
+    assert old._hooks == [] and old._wait_hooks == []
+    snap = old.flat_grad.clone() if hasattr(old, "flat_grad") else None
+    fired_before = list(old._fired)
+    new = Zero1Engine(m, lr=1e-2, bucket_mb=0.001)
+    new.zero_grad(); _loss(m, x, y).backward()
+    assert old._fired == fired_before and all(g is None for g in old._stash)      # the old engine saw nothing of this backward
+    if snap is not None:
+        assert torch.equal(old.flat_grad, snap)
+    new.step()
+    new.close()
+
+
 def test_gradient_gather_modes_agree_and_unused_parameters_get_zero():
     """zero_grad(set_to_none=True) (bucket-wise multi-tensor gather of autograd's gradient tensors) and
     set_to_none=False (in-place accumulation into the zeroed flat buffer) give the same update; a parameter that

@@ -58,13 +58,15 @@ def test_forward_from_state(emu_lib):
 
 
 @pytest.mark.parametrize("mode,T", [(6, 48), (7, 16), (7, 32), (7, 96), (8, 16), (8, 32), (8, 48), (8, 64), (8, 80), (8, 160), (9, 16), (9, 32), (9, 48), (9, 64), (9, 80), (9, 160),
-                                    (10, 16), (10, 32), (10, 48), (10, 64), (10, 80), (10, 160)])
+                                    (10, 16), (10, 32), (10, 48), (10, 64), (10, 80), (10, 160),
+                                    (11, 16), (11, 32), (11, 48), (11, 64), (11, 80), (11, 160), (12, 16), (12, 32), (12, 48), (12, 64), (12, 80), (12, 160)])
 def test_backward_chunked(emu_lib, mode, T):
     """Chunked MFMA backward kernels run lane-exactly on the host: 6 = the producer / consumer schedule (wkv7_bwd_v5.h), 7 = the three-stage wave pipeline (wkv7_bwd_v6.h;
     1, 2 and 6 chunks: pipeline shorter than, equal to and longer than its depth), 8 = the same pipeline with the full-row memory
     role (wkv7_bwd_v7.h: rows by LDS-DMA, single-buffered staging and result images; 1 .. 5 chunks = only ragged steps, 10 chunks =
     five steady-state steps), 9 = wkv7_bwd_v8.h (one copy of dL/dS handed from the I to the J waves as an operand image, the decay-gradient
-    term as an MFMA diagonal, the T chain on P wave 0, single-buffered S0)."""
+    term as an MFMA diagonal, the T chain on P wave 0, single-buffered S0), 10 = 9 with the score pieces a step ahead on the P waves, 11 / 12 = 9 / 10 with
+    the element-wise tail and the gradient stores on the J waves (JTAIL)."""
     B, H = 1, 2
     w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=7 + mode)
     _, s, sa = wkv7_c.forward(w, q, k, v, z, a)

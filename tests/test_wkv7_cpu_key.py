@@ -57,3 +57,32 @@ def test_threads_do_not_change_the_result(monkeypatch):
         outs.append([y] + grads)
     for x, y in zip(*outs):
         assert torch.equal(x, y)
+
+
+def test_the_host_pool_survives_a_fork():
+    """The persistent host thread pool of csrc/wkv7_host.hip after os.fork(): the child inherits a pool whose worker threads do not
+    exist there (the call blocked forever).  A pool abandons the parent's state when the pid changes."""
+    import os
+    import signal
+    B, T, H = 2, 32, 4
+    w, q, k, v, z, a, _ = make_inputs(B, T, H, seed=3)
+
+    def fwd():
+        y, s, sa = torch.empty_like(v), torch.empty(B, H, T // 16, 64, 64), torch.empty(B, T, H, 64)
+        torch.ops.wind_backstepping.forward(w, q, k, v, z, a, y, s, sa)
+        return y
+
+    y0 = fwd()                                       # the parent's pool exists now (B * H = 8 tasks: more than one thread)
+    rd, wr = os.pipe()
+    pid = os.fork()
+    if pid == 0:                                     # child: must neither hang nor differ
+        try:
+            signal.alarm(20)
+            ok = torch.equal(fwd(), y0) and torch.equal(fwd(), y0)
+            os.write(wr, b"1" if ok else b"0")
+        finally:
+            os._exit(0)
+    os.close(wr)
+    _, status = os.waitpid(pid, 0)
+    assert os.read(rd, 1) == b"1", f"forked child did not finish the CPU op (wait status {status})"
+    assert torch.equal(fwd(), y0)                    # the parent's pool is untouched

@@ -19,6 +19,7 @@ TOL = 1e-3
 TOL_TPAR = 1e-3
 FLIP_Y, FLIP_G, FLIP_W, FLIP_SEQ = 0.01, 0.012, 0.03, 0.015
 NAMES = ["dw", "dq", "dk", "dv", "dz", "da"]
+BWD_DISPATCH = {True: 9, False: 8}      # what vrwkv_wkv7_backward_bf16 picks by default: more than one round of workgroups (B x H > 256) | at most one
 
 
 @pytest.fixture(scope="module")
@@ -66,7 +67,7 @@ def test_forward_parity(hip_lib, dev, B, T, H, variant):
     assert rel_rms(sa.cpu(), sar) < 2e-5
 
 
-@pytest.mark.parametrize("variant", [5, 6, 7, 8, 9])       # 9: the default (v8 + score pieces a step ahead); 8: wkv7_bwd_v8.h; 7: wkv7_bwd_v7.h (full-row memory role); wkv7_bwd_v5.h (8 waves; also the sequence-parallel kernel), wkv7_bwd_v6.h (12-wave pipeline, default)
+@pytest.mark.parametrize("variant", [5, 6, 7, 8, 9, 10, 11])       # 10 / 11: 9 / 8 with the element-wise tail on the J waves; 9: the default (v8 + score pieces a step ahead); 8: wkv7_bwd_v8.h; 7: wkv7_bwd_v7.h (full-row memory role); wkv7_bwd_v5.h (8 waves; also the sequence-parallel kernel), wkv7_bwd_v6.h (12-wave pipeline, default)
 @pytest.mark.parametrize("B,T,H", [(1, 16, 1), (2, 64, 3), (1, 384, 12), (3, 208, 5)])
 def test_backward_parity(hip_lib, dev, B, T, H, variant):
     w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=B * 77 + T + H)
@@ -92,7 +93,7 @@ def test_hip_kernels_against_reference_loop_fixture_n64(hip_lib, dev):
     torch.cuda.synchronize()
     bf16_close(y, g["out"], "y vs reference loop", tol=TOL, max_flip=FLIP_Y)
     assert rel_rms(s[:, :, -1].transpose(-1, -2).double().cpu(), g["final_state"]) < 2e-5
-    for variant in (5, 6, 7, 8):
+    for variant in (5, 6, 7, 8, 9, 10, 11):
         hip_lib.vrwkv_wkv7_set_backward_variant(variant)
         try:
             outs = _capi_backward(hip_lib, *ins, g["dy"].to(dev), s, sa)
@@ -228,6 +229,29 @@ def test_cfg3_fullsize_backward_against_oracle(hip_lib, dev):
     assert rel_rms(s.cpu(), sr) < 2e-5 and rel_rms(sa.cpu(), sar) < 2e-5
     for n, o, r in zip(NAMES, outs, ref):
         assert rel_rms(o.float().cpu(), r.float()) < TOL, n
+
+
+@pytest.mark.parametrize("B,T,H", [(16, 2624, 32), (8, 6400, 32)])
+def test_bench_dispatch_against_oracle(hip_lib, dev, B, T, H):
+    """The launches bench.py times -- cfg 3 at micro-batch 16 (B x H = 512: two rounds of workgroups) and cfg 5 at micro-batch 8
+    (B x H = 256) -- with NO variant forced: whatever the launchers pick for these sizes (asserted through
+    vrwkv_wkv7_last_variant), every head, forward outputs, both by-products and all six gradients against the C oracle
+    (wkv7_cuda.cu:10-130 restated; seconds on the GPU box's host cores)."""
+    assert hip_lib.vrwkv_wkv7_set_forward_variant(-1) == 0 and hip_lib.vrwkv_wkv7_set_backward_variant(-1) == 0
+    w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=B + T)
+    yr, sr, sar = wkv7_c.forward(w, q, k, v, z, a)
+    ref = wkv7_c.backward(w, q, k, v, z, a, dy, sr, sar)
+    d = [x.to(dev) for x in (w, q, k, v, z, a, dy)]
+    y, s, sa = _capi_forward(hip_lib, *d[:6])
+    assert hip_lib.vrwkv_wkv7_last_variant(0) == 7                    # wkv7_fwd_v4.h for B x H > 128
+    outs = _capi_backward(hip_lib, *d, s, sa)
+    torch.cuda.synchronize()
+    assert hip_lib.vrwkv_wkv7_last_variant(1) == BWD_DISPATCH[B * H > 256], hip_lib.vrwkv_wkv7_last_variant(1)
+    bf16_close(y, yr.float(), f"bench dispatch y {B}x{T}x{H}", tol=TOL, max_flip=FLIP_Y)
+    assert rel_rms(s.cpu(), sr) < 2e-5 and rel_rms(sa.cpu(), sar) < 2e-5
+    del s, sa, sr, sar
+    for n, o, r in zip(NAMES, outs, ref):
+        bf16_close(o, r.float(), f"bench dispatch {n} {B}x{T}x{H}", tol=TOL, max_flip=FLIP_W if n in ("dw", "dz") else FLIP_G)
 
 
 @pytest.mark.parametrize("tpar", [False, True])

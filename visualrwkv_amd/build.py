@@ -144,8 +144,18 @@ def build_host(force: bool = False) -> str:
     header declares its two entry points.)"""
     src = os.path.join(CSRC, "wkv7_host.hip")
     hdr = os.path.join(REPO_DIR, "include", "visualrwkv_hip.h")
-    if not force and os.path.exists(HOST_LIB_PATH) and os.path.getmtime(HOST_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        return HOST_LIB_PATH
+    h = hashlib.sha256()
+    for d in (src, hdr):
+        with open(d, "rb") as f:
+            h.update(f.read())
+    digest, hash_path = h.hexdigest(), HOST_LIB_PATH + ".hash"       # content hash, as for the HIP library: mtimes do not survive a copy
+    if not force and os.path.exists(HOST_LIB_PATH):
+        try:
+            with open(hash_path) as f:
+                if f.read().strip() == digest:
+                    return HOST_LIB_PATH
+        except OSError:
+            pass
     cxx = shutil.which("g++") or shutil.which("clang++") or shutil.which("c++")
     if cxx is None:
         raise RuntimeError("no host C++ compiler (g++ / clang++) found for libvisualrwkv_host.so")
@@ -156,6 +166,8 @@ def build_host(force: bool = False) -> str:
             subprocess.run([cxx, "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-x", "c++", "-I", os.path.join(REPO_DIR, "include"),
                             src, "-o", tmp], check=True)
             os.replace(tmp, HOST_LIB_PATH)
+            with open(hash_path, "w") as f:
+                f.write(digest)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return HOST_LIB_PATH

@@ -209,12 +209,12 @@ DEVFN void lds_dma16_sbase(const void* uniform_base, unsigned lane_byte_off, voi
 }
 // the lean form for inner loops: scalar base, 32-bit lane offset, compile-time byte offset (0 .. 4095) that the hardware adds to BOTH
 // the global address and the LDS address (lane l lands at M0 + IMM + 16 l; checked on gfx950: tests/test_probe_gpu.py), and M0
-// is NOT saved / restored -- the kernels that use it never give M0 to the compiler (gfx9 LDS instructions do not read it; the
-// disassembly of csrc/wkv7_capi.hip has no other M0 access), which saves two scalar moves per request: on gfx950 every instruction
+// is NOT saved / restored (it is declared clobbered instead: the compiler keeps nothing in M0 here -- gfx9 LDS instructions do not read
+// it -- so the clobber costs nothing today and stays correct if a later compiler or code change does use M0), which saves two scalar moves per request: on gfx950 every instruction
 // of any class takes an issue slot of its SIMD (profiles/r4_wkv7_pmc_v6_v8.txt), so they cost what VALU instructions cost
 template <int IMM> DEVFN void lds_dma16_lean(const void* uniform_base, unsigned lane_byte_off, unsigned lds_dst_uniform) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
-                 :: "v"(lane_byte_off), "s"(uniform_base), "s"(lds_dst_uniform), "n"(IMM) : "memory");
+                 :: "v"(lane_byte_off), "s"(uniform_base), "s"(lds_dst_uniform), "n"(IMM) : "memory", "m0");
 }
 // a wave-uniform pointer the compiler keeps in VGPRs (derived next to per-lane arithmetic) -> SGPR pair, for the "s" operands above
 DEVFN const void* uniform_ptr(const void* ptr) {

@@ -80,7 +80,10 @@ struct LdsV8 {
     float s0[N * N];                 // S0 of the J waves' next chunk (P waves' LDS-DMA, requested when flag 3 says the current one is in registers)
     uint16_t dsi[2][SIMG];           // hi, lo of diag(c_L) dS as the I waves hold it at the start of their step: [i][j] bf16, swizzled like
                                      // every image (I waves -> the J waves' operands one step later; flag 3 hands it back)
-    float res[4][IMG];               // J -> P: dZt dQt dAh dKh before the decay factors, fp32 (single: flag 4 hands it back)
+    union {
+        float res[4][IMG];           // J -> P: dZt dQt dAh dKh before the decay factors, fp32 (single: flag 4 hands it back)
+        float x2r[3][IMG];           // JTAIL: log2 c_t [t][j] of chunk c in slot c % 3 (P waves -> the J waves' tail two steps later)
+    };
     float glast[2][N];               // sum_i dS_L[i][j] S_L[i][j] at the chunk's last token, by chunk parity
     unsigned flag[8];                // 0: M_qa, M_qk, M_zk written (3 per step)  1: dM written (3)  2: T written (1)  3: J operands split (4)
                                      // 4: tail has read `res` (4)  5: P waves hold their staging pieces (4)      (flag 1: four I waves since the score-gradient pieces were re-dealt)
@@ -205,6 +208,41 @@ DEVFN void tail8(LdsV8& lds, int par, const TailQ& tr, const BwdArgs& p, size_t 
     *out(p.da) = make_uint2(cvt_pk_bf16(da[0], da[1]), cvt_pk_bf16(da[2], da[3]));
 }
 
+// The same tail on the J waves (JTAIL): dZt dQt dAh dKh arrive in registers (lane = token c16, 4 channels 16w + 4g ..), the operands of
+// the decay-gradient integrand come from the chunk's operand images (hi + lo; this lane's own 8-byte pieces, the layout the P waves wrote),
+// log2 c_t from the ring; glast[cj & 1] was written by this wave a few instructions ago (wave_lds_fence orders the exchange).
+DEVFN void jtail8(LdsV8& lds, const ChunkImg7& B, int cj, const f32x4& dZt, const f32x4& dQt, const f32x4& dAh, const f32x4& dKh,
+                  const BwdArgs& p, size_t u, unsigned lane_boff, int c16, int w, int g, const LaneAddr& la) {
+    float zh[4], zl[4], qh[4], ql[4], ah[4], al[4], kh[4], kl[4];
+    unpack4(ld8(&B.opnd[0][la.own]), zh); unpack4(ld8(&B.opnd[1][la.own]), zl);
+    unpack4(ld8(&B.opnd[2][la.own]), qh); unpack4(ld8(&B.opnd[3][la.own]), ql);
+    unpack4(ld8(&B.opnd[4][la.own]), ah); unpack4(ld8(&B.opnd[5][la.own]), al);
+    unpack4(ld8(&B.opnd[6][la.own]), kh); unpack4(ld8(&B.opnd[7][la.own]), kl);
+    const float4 x4 = *reinterpret_cast<const float4*>(&lds.x2r[cj % 3][la.f32]);
+    wave_lds_fence();
+    const float4 gl4 = *reinterpret_cast<const float4*>(&lds.glast[cj & 1][16 * w + 4 * g]);
+    const float x2v[4] = {x4.x, x4.y, x4.z, x4.w}, glv[4] = {gl4.x, gl4.y, gl4.z, gl4.w};
+    float dz[4], dq[4], da[4], dk[4], dw[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x2 = x2v[e], l2 = x2 - dpp_shr1_fill(x2, 0.f);        // log2 w_t = the difference of log2 c_t along t
+        const float cc = fast_exp2(x2), ic = fast_exp2(-x2);
+        const float cp = dpp_shr1_fill(cc, 1.f);
+        dz[e] = dZt[e] * cp; dq[e] = dQt[e] * cc; da[e] = dAh[e] * ic; dk[e] = dKh[e] * ic;
+        // dq q - da a - dk k + (dz z)(t+1) with q = Qt / c_t etc.: the decay factors cancel
+        float gt = dQt[e] * (qh[e] + ql[e]) - dAh[e] * (ah[e] + al[e]) - dKh[e] * (kh[e] + kl[e]) + dpp_shl<1>(dZt[e] * (zh[e] + zl[e]));
+        if (c16 == 15) gt += glv[e];
+        gt += dpp_shl<1>(gt); gt += dpp_shl<2>(gt); gt += dpp_shl<4>(gt); gt += dpp_shl<8>(gt);   // suffix sum over t
+        dw[e] = gt * (l2 * LN2);
+    }
+    auto out = [&](uint16_t* base) { return reinterpret_cast<uint2*>(reinterpret_cast<char*>(base + u) + lane_boff); };   // uniform base + lane offset
+    *out(p.dw) = make_uint2(cvt_pk_bf16(dw[0], dw[1]), cvt_pk_bf16(dw[2], dw[3]));
+    *out(p.dq) = make_uint2(cvt_pk_bf16(dq[0], dq[1]), cvt_pk_bf16(dq[2], dq[3]));
+    *out(p.dk) = make_uint2(cvt_pk_bf16(dk[0], dk[1]), cvt_pk_bf16(dk[2], dk[3]));
+    *out(p.dz) = make_uint2(cvt_pk_bf16(dz[0], dz[1]), cvt_pk_bf16(dz[2], dz[3]));
+    *out(p.da) = make_uint2(cvt_pk_bf16(da[0], da[1]), cvt_pk_bf16(da[2], da[3]));
+}
+
 // ------------------------------------------------------------------------------------------ kernel
 // dbg (PROF): as wkv7_bwd_v6.h.  SKIP (timing experiments only, results are garbage): bit 0 P does nothing, bit 1 I only raises
 // its flags, bit 2 J does nothing.
@@ -215,7 +253,15 @@ DEVFN void tail8(LdsV8& lds, int par, const TailQ& tr, const BwdArgs& p, size_t 
 // images are built -- where those waves stood ~1.9k cycles at the barrier (profiles/r4b_wkv7_phases_waves_v8.jsonl) -- instead of by I
 // waves 1-3 at the start of the next step, where they delayed the i-split's chain by 1.6-1.8k cycles.  The P waves prepare the
 // images BEFORE their tail for that (the queue entry of the prepare is assigned after the tail has consumed the old one).
-template <bool PROF, int PI = VRWKV_V8_PI, int PJ = VRWKV_V8_PJ, int PP = VRWKV_V8_PP, int SKIP = 0, bool TBF16 = true, int PT = PP, bool AHEAD = false>
+// JTAIL (variant 10): the element-wise tail and the five gradient stores run on the J waves, in the step in which they form dZt dQt dAh dKh
+// -- the results never leave their registers -- instead of on the P waves a step later.  One wave issues an instruction every ~5 cycles
+// whatever the other two waves of its SIMD do (profiles/r3_valu_rate.json: 5.5 cycles per VALU instruction at one wave per SIMD, 2.1 at
+// three), so a step lasts as long as its LONGEST wave: per step the P waves issued ~660 (wave 0, with the T chain) / ~545 instructions,
+// the I waves ~445, the J waves ~225 (ISA of the AHEAD instantiation), and the P waves reached the barrier last with 0.2-0.3k cycles of
+// slack (profiles/r4b_wkv7_phases_waves_v8_ahead.jsonl).  The tail is ~165 of them.  On the J waves it needs Zt Qt Ah Kh of the chunk
+// (hi + lo from the operand images: dq q = dQt Qt etc., so the raw inputs are not needed) and log2 c_t (the P waves leave it in a
+// ring of three fp32 images that takes the place of `res`): no three-deep register queue on the P waves, no `res` round trip, no flag 4.
+template <bool PROF, int PI = VRWKV_V8_PI, int PJ = VRWKV_V8_PJ, int PP = VRWKV_V8_PP, int SKIP = 0, bool TBF16 = true, int PT = PP, bool AHEAD = false, bool JTAIL = false>
 __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
     LdsV8& lds = *reinterpret_cast<LdsV8*>(dyn_lds());
     const int T = p.T, H = p.H;
@@ -228,7 +274,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
     const unsigned bh = blockIdx.x;
     const size_t head_base = ((size_t)(bh / H) * T * H + (bh % H)) * N;
     const float* sbase = p.s + (size_t)bh * nchunk * N * N;
-    const int nsteps = nchunk + 3;
+    const int nsteps = nchunk + (JTAIL ? 2 : 3);       // the last step of the P-tail schedule holds only the tail of chunk 0
     const LaneAddr la = lane_addr(c16, g, w);
     const unsigned out_off = (unsigned)c16 * ts + 16u * w + 4u * g;        // token c16, channels 16w+4g..+3
     WKV_STAMP_DECL
@@ -298,11 +344,15 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                         if (w == 1) s0_lean<0>(lds, sc, ll); else if (w == 2) s0_lean<1>(lds, sc, ll); else if (w == 3) s0_lean<2>(lds, sc, ll);
                     } else if (cd >= 0 && cd <= nchunk - 1) dma_state(lds.s0, cd > 0 ? sbase + (size_t)(cd - 1) * N * N : nullptr, k0, k1, lane);
                 }
-                if (FULL || (ct >= 0 && ct <= nchunk - 1)) tail8(lds, ct & 1, qt, p, head_base + (size_t)ct * L * ts, lane_boff, c16, w, g, la);
+                if (!JTAIL && (FULL || (ct >= 0 && ct <= nchunk - 1))) tail8(lds, ct & 1, qt, p, head_base + (size_t)ct * L * ts, lane_boff, c16, w, g, la);
                 WKV_STAMP(0)
-                if (SHIFT) { q2 = q1; q1 = q0; }
+                if (SHIFT && !JTAIL) { q2 = q1; q1 = q0; }
                 TailQ& qn = SHIFT ? q0 : qt;
-                if (do_prep) {
+                if (do_prep && JTAIL) {
+                    if (!AHEAD) dd = prep8(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la);
+                    *reinterpret_cast<float4*>(&lds.x2r[cp % 3][la.f32]) = make_float4(dd.x2[0], dd.x2[1], dd.x2[2], dd.x2[3]);
+                }
+                if (do_prep && !JTAIL) {
                     if (!AHEAD) dd = prep8(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la);
                     qn.q = raw.q; qn.k = raw.k; qn.z = raw.z; qn.a = raw.a;
                     qn.x2[0] = dd.x2[0]; qn.x2[1] = dd.x2[1]; qn.x2[2] = dd.x2[2]; qn.x2[3] = dd.x2[3];
@@ -319,7 +369,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                     wkv7v6::scores6<true>(lds, lds.b[cp % 3], w, c16, g, la);
                 }
                 WKV_STAMP(1)
-                if (FULL) vmem_wait<5>(); else vmem_drain();
+                if (FULL && !JTAIL) vmem_wait<5>(); else vmem_drain();      // JTAIL: this role issues requests only
             } else if (w == 0 && cd >= 0 && cd <= nchunk - 1) lds_flag_add(&lds.flag[2]);
             WKV_STAMP(2)
             block_sync_lds();
@@ -328,7 +378,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
         int n = 0;
         for (; n < 3 && n < nsteps; ++n) pstep(n, BoolTag<false>{}, q2, BoolTag<true>{});
 #if VRWKV_V8_ROTATE
-        for (; n + 2 < nchunk - 1; n += 3) {            // three steps: the entries rotate through the names and are back in place
+        for (; !JTAIL && n + 2 < nchunk - 1; n += 3) {  // three steps: the entries rotate through the names and are back in place (JTAIL has no queue)
             pstep(n, BoolTag<true>{}, q2, BoolTag<false>{});
             pstep(n + 1, BoolTag<true>{}, q1, BoolTag<false>{});
             pstep(n + 2, BoolTag<true>{}, q0, BoolTag<false>{});
@@ -633,11 +683,15 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
             }
             // results: lane = token c16, registers = channels 16w + 4g + e -> the fp32 image of the P waves' tail, once the tail of
             // the chunk before (this step's, steps 3 ..) has read it: 4 P waves per tail
-            if (!(SKIP & 1) && n >= 3) lds_flag_wait(&lds.flag[4], 4u * (unsigned)(n - 2));
-            *reinterpret_cast<float4*>(&lds.res[0][la.f32]) = make_float4(dZt[0], dZt[1], dZt[2], dZt[3]);
-            *reinterpret_cast<float4*>(&lds.res[1][la.f32]) = make_float4(dQt[0], dQt[1], dQt[2], dQt[3]);
-            *reinterpret_cast<float4*>(&lds.res[2][la.f32]) = make_float4(dAh[0], dAh[1], dAh[2], dAh[3]);
-            *reinterpret_cast<float4*>(&lds.res[3][la.f32]) = make_float4(dKh[0], dKh[1], dKh[2], dKh[3]);
+            if (JTAIL) {
+                jtail8(lds, B, cj, dZt, dQt, dAh, dKh, p, head_base + (size_t)cj * L * ts, out_off * 2u, c16, w, g, la);
+            } else {
+                if (!(SKIP & 1) && n >= 3) lds_flag_wait(&lds.flag[4], 4u * (unsigned)(n - 2));
+                *reinterpret_cast<float4*>(&lds.res[0][la.f32]) = make_float4(dZt[0], dZt[1], dZt[2], dZt[3]);
+                *reinterpret_cast<float4*>(&lds.res[1][la.f32]) = make_float4(dQt[0], dQt[1], dQt[2], dQt[3]);
+                *reinterpret_cast<float4*>(&lds.res[2][la.f32]) = make_float4(dAh[0], dAh[1], dAh[2], dAh[3]);
+                *reinterpret_cast<float4*>(&lds.res[3][la.f32]) = make_float4(dKh[0], dKh[1], dKh[2], dKh[3]);
+            }
         }
         WKV_STAMP(2)
         block_sync_lds();

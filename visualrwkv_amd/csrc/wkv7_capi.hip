@@ -19,6 +19,7 @@ namespace {
 
 int g_fwd_variant = -1;
 int g_bwd_variant = -1;
+int g_last_fwd = 0, g_last_bwd = 0;     // what the last launch of each direction resolved to (vrwkv_wkv7_last_variant)
 // T chain on the bf16 matrix core (2) + producer priority 2 (4; same-box A/B: 1.18 -> 1.09 ms) + priorities swapped in
 // segment 1, where the producers have ~1.2k cycles of slack per chunk and the consumers none (128; 1.09 -> 1.04 ms)
 constexpr int BWD_V5_MODE = 2 + 4 + 128;
@@ -71,10 +72,12 @@ int vrwkv_wkv7_set_forward_variant(int variant) {
 }
 
 int vrwkv_wkv7_set_backward_variant(int variant) {
-    if (variant != -1 && variant != 5 && variant != 6 && variant != 7 && variant != 8 && variant != 9 && !(variant >= 60 && variant < 90)) return VRWKV_EINVAL;   // see include/visualrwkv_hip.h
+    if (variant != -1 && !(variant >= 5 && variant <= 11) && !(variant >= 60 && variant < 90)) return VRWKV_EINVAL;   // see include/visualrwkv_hip.h
     g_bwd_variant = variant;
     return VRWKV_OK;
 }
+
+int vrwkv_wkv7_last_variant(int backward) { return backward ? g_last_bwd : g_last_fwd; }
 
 int vrwkv_wkv7_forward_bf16(int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
                             const void* z, const void* a, void* y, float* s, float* sa, void* stream) {
@@ -103,12 +106,14 @@ int vrwkv_wkv7_forward_bf16(int B, int T, int H, const void* w, const void* q, c
             hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv7f4::LdsF4));
             if (e4 != hipSuccess) return (int)e4;
             hipLaunchKernelGGL(k4, grid, dim3(512), sizeof(wkv7f4::LdsF4), st, p);
+            g_last_fwd = 7;
             return finish_launch();
         }
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)sizeof(wkv7c::LdsF));
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(kern, g2, dim3(512), sizeof(wkv7c::LdsF), st, p);
+        g_last_fwd = g2.x != grid.x ? 6 : g_fwd_variant == -1 ? 4 : g_fwd_variant;      // 6: two workgroups per head; 4: the default instantiation of wkv7_fwd_v3.h
     }
     return finish_launch();
 }
@@ -153,11 +158,13 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H, const void* w, const void* q, 
     // for a single round of workgroups (B x H <= 256: 9 measured +0.3 ... +1.8 % there); profiles/r4_wkv7_ab.jsonl, r4c_wkv7_ab.jsonl
     int var = g_bwd_variant == -1 ? ((long)B * H > 256 ? BWD_DEFAULT : 8) : g_bwd_variant;
     const bool fits32 = (unsigned long long)B * T * H * 64ull * 4ull < (1ull << 32);      // wkv7_bwd_v8.h uses 32-bit byte offsets inside a tensor
-    if (!fits32 && (var == 8 || var == 9 || var >= 80)) var = 6;
-    if (var == 8 || var == 9 || (var >= 80 && var < 90)) {
+    if (!fits32 && (var >= 8 && var <= 11 || var >= 80)) var = 6;
+    if ((var >= 8 && var <= 11) || (var >= 80 && var < 90)) {
         // one copy of dL/dS, T chain on P wave 0, full-row memory role, 12 waves (wkv7_bwd_v8.h)
         void (*kern)(wkv7::BwdArgs) = &wkv7v8::bwd_kernel_v8<false>;
         if (var == 9) kern = &wkv7v8::bwd_kernel_v8<false, VRWKV_V8_PI, VRWKV_V8_PJ, VRWKV_V8_PP, 0, true, VRWKV_V8_PP, true>;      // score pieces a step ahead on the P waves
+        if (var == 10) kern = &wkv7v8::bwd_kernel_v8<false, VRWKV_V8_PI, VRWKV_V8_PJ, VRWKV_V8_PP, 0, true, VRWKV_V8_PP, true, true>;      // 9 with the tail on the J waves
+        if (var == 11) kern = &wkv7v8::bwd_kernel_v8<false, VRWKV_V8_PI, VRWKV_V8_PJ, VRWKV_V8_PP, 0, true, VRWKV_V8_PP, false, true>;      // 8 with the tail on the J waves
 #ifdef VRWKV_V6_EXPERIMENTS   // role-timing builds: one or two roles switched off, results garbage
         switch (g_bwd_variant) {
             case 81: kern = &wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 1>; break;     // no P
@@ -219,7 +226,9 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H, const void* w, const void* q, 
                                            (int)sizeof(wkv7v5::LdsV5));
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(kern, grid, dim3(512), sizeof(wkv7v5::LdsV5), st, p);
+        var = 5;
     }
+    g_last_bwd = var;
     return finish_launch();
 }
 

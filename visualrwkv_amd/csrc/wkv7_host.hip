@@ -18,8 +18,11 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
+
+#include <unistd.h>
 
 #include "../../include/visualrwkv_hip.h"
 
@@ -42,7 +45,20 @@ inline void st(float* p, float x) { *p = x; }
 // A persistent pool of host threads (created on first use, reused by every call: the op runs once per layer and direction) that
 // hands out task indices through one atomic counter.  Nothing throws across the C boundary: a pool that cannot be created runs the
 // tasks on the calling thread.
+// fork(): only the forking thread exists in the child, so a pool inherited from the parent lists workers that are not there and a
+// call would wait for them forever.  All state lives in a heap object tagged with the pid that created it; a call from another
+// pid abandons that object (no joins, no destructors: its threads and possibly-held locks belong to the parent) and starts a new one.
 class Pool {
+    struct State {
+        std::mutex call_mu, mu;
+        std::condition_variable cv, done;
+        std::vector<std::thread> workers;
+        std::function<void(int)>* fn = nullptr;
+        std::atomic<int> next{0};
+        int n_tasks = 0, active = 0, wanted = 0;
+        unsigned long epoch = 0;
+        bool stop = false;
+    };
 public:
     static Pool& get() { static Pool p; return p; }
     // run body(0 .. n_tasks-1) on up to n_threads threads (0: hardware_concurrency), the caller included
@@ -51,61 +67,77 @@ public:
         if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
         if (n_threads > n_tasks) n_threads = n_tasks;
         if (n_threads <= 1) { for (int i = 0; i < n_tasks; ++i) body(i); return; }
-        std::lock_guard<std::mutex> call(call_mu_);                 // one parallel region at a time
-        grow(n_threads - 1);
-        const int helpers = (int)std::min<size_t>(workers_.size(), (size_t)(n_threads - 1));
+        State* s = state();
+        if (!s) { for (int i = 0; i < n_tasks; ++i) body(i); return; }
+        std::lock_guard<std::mutex> call(s->call_mu);               // one parallel region at a time
+        grow(s, n_threads - 1);
+        const int helpers = (int)std::min<size_t>(s->workers.size(), (size_t)(n_threads - 1));
         std::function<void(int)> fn = body;
         {
-            std::lock_guard<std::mutex> lk(mu_);
-            fn_ = &fn; n_tasks_ = n_tasks; next_.store(0); active_ = helpers; wanted_ = helpers; ++epoch_;
+            std::lock_guard<std::mutex> lk(s->mu);
+            s->fn = &fn; s->n_tasks = n_tasks; s->next.store(0); s->active = helpers; s->wanted = helpers; ++s->epoch;
         }
-        cv_.notify_all();
-        for (int i = next_.fetch_add(1); i < n_tasks; i = next_.fetch_add(1)) body(i);
-        std::unique_lock<std::mutex> lk(mu_);
-        done_.wait(lk, [&] { return active_ == 0; });
-        fn_ = nullptr;
+        s->cv.notify_all();
+        for (int i = s->next.fetch_add(1); i < n_tasks; i = s->next.fetch_add(1)) body(i);
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->done.wait(lk, [&] { return s->active == 0; });
+        s->fn = nullptr;
     }
 private:
     Pool() = default;
     ~Pool() {
-        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++epoch_; }
-        cv_.notify_all();
-        for (auto& t : workers_) if (t.joinable()) t.join();
+        State* s = st_.load();
+        if (!s || pid_.load() != (long)getpid()) return;           // a forked child never joins the parent's threads
+        { std::lock_guard<std::mutex> lk(s->mu); s->stop = true; ++s->epoch; }
+        s->cv.notify_all();
+        for (auto& t : s->workers) if (t.joinable()) t.join();
+        delete s;
     }
-    void grow(int n) {
-        while ((int)workers_.size() < n) {
+    // the state of THIS process (nullptr: allocation failed, run serially)
+    State* state() {
+        const long me = (long)getpid();
+        State* s = st_.load(std::memory_order_acquire);
+        if (s && pid_.load(std::memory_order_acquire) == me) return s;
+        while (swap_.exchange(true, std::memory_order_acquire)) std::this_thread::yield();      // not a std::mutex: one held across a fork stays held in the child
+        s = st_.load();
+        if (!s || pid_.load() != me) {
+            State* fresh = new (std::nothrow) State;               // the old one (if any) is the parent's: abandoned, not destroyed
+            st_.store(fresh, std::memory_order_release);
+            pid_.store(me, std::memory_order_release);
+            s = fresh;
+        }
+        swap_.store(false, std::memory_order_release);
+        return s;
+    }
+    static void grow(State* s, int n) {
+        while ((int)s->workers.size() < n) {
             try {
-                const int id = (int)workers_.size();
-                workers_.emplace_back([this, id] { loop(id); });
+                const int id = (int)s->workers.size();
+                s->workers.emplace_back([s, id] { loop(s, id); });
             } catch (...) { break; }                              // out of threads: run with what exists
         }
     }
-    void loop(int id) {
+    static void loop(State* s, int id) {
         unsigned long seen = 0;
         for (;;) {
             std::function<void(int)>* fn;
             int n;
             {
-                std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return epoch_ != seen; });
-                seen = epoch_;
-                if (stop_) return;
-                if (id >= wanted_) continue;                      // more workers exist than this call asked for
-                fn = fn_; n = n_tasks_;
+                std::unique_lock<std::mutex> lk(s->mu);
+                s->cv.wait(lk, [&] { return s->epoch != seen; });
+                seen = s->epoch;
+                if (s->stop) return;
+                if (id >= s->wanted) continue;                    // more workers exist than this call asked for
+                fn = s->fn; n = s->n_tasks;
             }
-            for (int i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) (*fn)(i);
-            std::lock_guard<std::mutex> lk(mu_);
-            if (--active_ == 0) done_.notify_one();
+            for (int i = s->next.fetch_add(1); i < n; i = s->next.fetch_add(1)) (*fn)(i);
+            std::lock_guard<std::mutex> lk(s->mu);
+            if (--s->active == 0) s->done.notify_one();
         }
     }
-    std::mutex call_mu_, mu_;
-    std::condition_variable cv_, done_;
-    std::vector<std::thread> workers_;
-    std::function<void(int)>* fn_ = nullptr;
-    std::atomic<int> next_{0};
-    int n_tasks_ = 0, active_ = 0, wanted_ = 0;
-    unsigned long epoch_ = 0;
-    bool stop_ = false;
+    std::atomic<State*> st_{nullptr};
+    std::atomic<long> pid_{0};
+    std::atomic<bool> swap_{false};
 };
 
 template <class F>

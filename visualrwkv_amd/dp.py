@@ -148,6 +148,7 @@ class Zero1Engine:
         # copy when its last parameter arrives.
         self._stash = [None] * len(ordered)
         self._fired = [False] * len(ordered)
+        self._gloo_ok = {}
         self._hooks = []
         for k, p in enumerate(ordered):
             self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(k)))
@@ -246,13 +247,26 @@ class Zero1Engine:
         backend = dist.get_backend(self.pg)
         if backend == "nccl":
             dist.reduce_scatter_tensor(piece, buf, op=dist.ReduceOp.SUM, group=self.pg)   # in place on own piece
-        else:   # gloo has no reduce-scatter: all-reduce in the buffer's own dtype (bf16 sums in bf16, like RCCL), keep the own slice
+        elif self._gloo_native_dtype(buf.dtype):   # gloo has no reduce-scatter: all-reduce in the buffer's own dtype (bf16 sums in bf16, like RCCL), keep the own slice
+            dist.all_reduce(buf, group=self.pg)
+        else:                                    # a gloo build without reductions in this dtype: sum in fp32, round once
+            wide = buf.float()
+            dist.all_reduce(wide, group=self.pg)
+            buf.copy_(wide)
+
+    def _gloo_native_dtype(self, dtype) -> bool:
+        """Whether this gloo build reduces `dtype` -- probed ONCE per dtype with a one-element all-reduce that every rank issues at the
+        same point (the first bucket of the first step), never by catching errors around a real collective: a communication failure
+        there must surface, not be retried."""
+        ok = self._gloo_ok.get(dtype)
+        if ok is None:
             try:
-                dist.all_reduce(buf, group=self.pg)
-            except RuntimeError:                 # a gloo build without bf16 reductions: sum in fp32, round once
-                wide = buf.float()
-                dist.all_reduce(wide, group=self.pg)
-                buf.copy_(wide)
+                dist.all_reduce(torch.zeros(1, dtype=dtype), group=self.pg)
+                ok = True
+            except RuntimeError:
+                ok = False
+            self._gloo_ok[dtype] = ok
+        return ok
 
     # ------------------------------------------------------------------ optimizer step
     @torch.no_grad()
@@ -343,6 +357,10 @@ class Zero1Engine:
     def close(self):
         """Detach the engine from its parameters: weight-gradient GEMMs stop writing into this engine's flat buffer (a model that
         outlives its engine, or gets a new one, must not keep the old buffer alive through its parameters)."""
+        for h in self._hooks + self._wait_hooks:      # or every later backward / forward of the model would still drive THIS engine
+            h.remove()
+        self._hooks, self._wait_hooks = [], []
+        self._stash = [None] * len(self._stash)
         for p in self.params:
             for attr in ("_vrwkv_flat_grad", "_vrwkv_flat_armed", "_vrwkv_wgrad_pending"):
                 if hasattr(p, attr):

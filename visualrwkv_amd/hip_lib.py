@@ -44,6 +44,7 @@ PROTOTYPES = {
     "vrwkv_wkv7_step_bf16": (_c_int, [_c_int] * 2 + [_c_void_p] * 9),
     "vrwkv_wkv7_set_forward_variant": (_c_int, [_c_int]),
     "vrwkv_wkv7_set_backward_variant": (_c_int, [_c_int]),
+    "vrwkv_wkv7_last_variant": (_c_int, [_c_int]),
     "vrwkv_mix_fwd_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int, _c_int] + [_c_void_p] * 4),
     "vrwkv_mix_fwd_prev_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int, _c_int] + [_c_void_p] * 5),
     "vrwkv_param_grad_ws_floats": (ctypes.c_long, [ctypes.c_long, _c_int, _c_int]),
@@ -127,14 +128,17 @@ def load_host() -> ctypes.CDLL:
     global _host_lib
     if _host_lib is not None:
         return _host_lib
-    path = os.environ.get("VRWKV_HOST_LIB", HOST_LIB_PATH)
-    if not os.path.exists(path):
+    path = os.environ.get("VRWKV_HOST_LIB")
+    if path is None:
         try:
             from .build import build_host
-            path = build_host()
-        except Exception:                                    # no host compiler here: the HIP library carries the same code
-            _host_lib = load()
-            return _host_lib
+            path = build_host()                              # no-op when the library is newer than its source; rebuilds a stale one
+        except Exception:
+            if os.path.exists(HOST_LIB_PATH):                # no host compiler here (e.g. a deployment box): use what travelled with the tree
+                path = HOST_LIB_PATH
+            else:                                            # the HIP library carries the same code
+                _host_lib = load()
+                return _host_lib
     lib = ctypes.CDLL(path)
     for name in ("vrwkv_wkv7_forward_host", "vrwkv_wkv7_backward_host"):
         res, args = PROTOTYPES[name]
