@@ -210,6 +210,16 @@ def cpu_baseline(n_embd, T):
                       f"runs after 1 warm-up, {t:.2f} s per block, scaled x24; head/loss/ViT/optimizer not included"}
 
 
+def _wkv7_kernel_name(backward: int) -> str:
+    """The kernel the last WKV7 launch of this process resolved to (vrwkv_wkv7_last_variant): what the roofline entry is about."""
+    from visualrwkv_amd import hip_lib
+    v = hip_lib.load().vrwkv_wkv7_last_variant(backward)
+    names = ({5: "wkv7v5::bwd_kernel_v5", 6: "wkv7v6::bwd_kernel_v6", 7: "wkv7v7::bwd_kernel_v7 (experiment)", 8: "wkv7v8::bwd_kernel_v8", 9: "wkv7v8::bwd_kernel_v8<AHEAD>",
+              10: "wkv7v8::bwd_kernel_v8<AHEAD,JTAIL> (experiment)", 11: "wkv7v8::bwd_kernel_v8<JTAIL> (experiment)"} if backward else
+             {7: "wkv7f4::fwd_kernel_v4", 6: "wkv7c::fwd_kernel_v3<two workgroups per head>"})
+    return names.get(v, f"wkv7c::fwd_kernel_v3<variant {v}>" if not backward else f"backward variant {v}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -401,12 +411,12 @@ def main():
             ms = sum(x for x, _ in kinds["bwd"]) / len(kinds["bwd"])
             elems = kinds["bwd"][0][1]
             ach = elems * BWD_B / ms / 1e6
-            out["roofline"] = {"bound": "hbm", "kernel": {"5": "wkv7v5::bwd_kernel_v5", "6": "wkv7v6::bwd_kernel_v6", "7": "wkv7v7::bwd_kernel_v7", "8": "wkv7v8::bwd_kernel_v8"}.get(os.environ.get("VRWKV_BWD_VARIANT", ""), "wkv7v8::bwd_kernel_v8<AHEAD>" if a.micro_bsz * MODELS[a.model]["n_embd"] // 64 > 256 else "wkv7v8::bwd_kernel_v8"), "achieved": ach, "peak": HBM_PEAK_GBPS,
+            out["roofline"] = {"bound": "hbm", "kernel": _wkv7_kernel_name(1), "achieved": ach, "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
                                "avg_ms": ms, "launches": len(kinds["bwd"]), "algorithmic_bytes": elems * BWD_B}
             if "fwd" in kinds:
                 msf = sum(x for x, _ in kinds["fwd"]) / len(kinds["fwd"])
-                out["roofline"]["fwd_kernel"] = {"kernel": "wkv7c::fwd_kernel_v3" if os.environ.get("VRWKV_FWD_VARIANT", "-1") not in ("-1", "7") else "wkv7f4::fwd_kernel_v4", "avg_ms": msf,
+                out["roofline"]["fwd_kernel"] = {"kernel": _wkv7_kernel_name(0), "avg_ms": msf,
                                                  "achieved": elems * FWD_B / msf / 1e6, "frac": elems * FWD_B / msf / 1e6 / HBM_PEAK_GBPS}
             copy = stream_copy_gbps(dev)                  # what a plain copy reaches on this box, random bytes
             out["roofline"]["stream_copy_GBps"] = copy

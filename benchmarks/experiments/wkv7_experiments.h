@@ -1,0 +1,62 @@
+// Backward variants that are NOT part of the product library: A/B partners and timing builds, compiled into wkv7_capi.hip /
+// wkv7_profile.hip only with -DVRWKV_V6_EXPERIMENTS -I benchmarks/experiments (benchmarks/build_alt.sh does that) and selected through
+// vrwkv_wkv7_set_backward_variant:
+//    7        wkv7_bwd_v7.h (the v6 schedule with the full-row memory role)
+//   10 / 11   wkv7_bwd_v8.h variants 9 / 8 with the element-wise tail and the gradient stores on the J waves (JTAIL; round 5: 1 - 9 % slower,
+//             profiles/r5_wkv7_jtail_*.json*)
+//   61 .. 67, 71 .. 77, 81 .. 88   v6 / v7 / v8 with one or two wave roles switched off (SKIP mask: 1 = no P, 2 = no I, 4 = no J,
+//             8 = no T chain; RESULTS ARE GARBAGE, timing only)
+#pragma once
+#include <wkv7_launch.h>
+#include <wkv7_bwd_v6.h>
+#include <wkv7_bwd_v7.h>
+#include <wkv7_bwd_v8.h>
+
+namespace wkv7exp {
+using namespace wkv7launch;
+
+inline bool is_experiment(int var) { return var == 7 || var == 10 || var == 11 || (var > 60 && var < 68) || (var > 70 && var < 78) || (var > 80 && var < 89); }
+
+inline int launch(int var, dim3 grid, hipStream_t st, const wkv7::BwdArgs& p) {
+    void (*kern)(wkv7::BwdArgs) = nullptr;
+    size_t lds = sizeof(wkv7v8::LdsV8);
+    switch (var) {
+        case 7: kern = &wkv7v7::bwd_kernel_v7<false>; lds = sizeof(wkv7v7::LdsV7); break;
+        case 10: kern = &wkv7v8::bwd_kernel_v8<false, VRWKV_V8_PI, VRWKV_V8_PJ, VRWKV_V8_PP, 0, true, VRWKV_V8_PP, true, true>; break;
+        case 11: kern = &wkv7v8::bwd_kernel_v8<false, VRWKV_V8_PI, VRWKV_V8_PJ, VRWKV_V8_PP, 0, true, VRWKV_V8_PP, false, true>; break;
+#define VRWKV_ROLE_CASES(base, KERN, LDS, ...)                                                        \
+        case base + 1: kern = &KERN<false, __VA_ARGS__ 1>; lds = sizeof(LDS); break;   /* no P */        \
+        case base + 2: kern = &KERN<false, __VA_ARGS__ 2>; lds = sizeof(LDS); break;   /* no I */        \
+        case base + 3: kern = &KERN<false, __VA_ARGS__ 4>; lds = sizeof(LDS); break;   /* no J */        \
+        case base + 4: kern = &KERN<false, __VA_ARGS__ 3>; lds = sizeof(LDS); break;   /* J alone */     \
+        case base + 5: kern = &KERN<false, __VA_ARGS__ 5>; lds = sizeof(LDS); break;   /* I alone */     \
+        case base + 6: kern = &KERN<false, __VA_ARGS__ 6>; lds = sizeof(LDS); break;   /* P alone */     \
+        case base + 7: kern = &KERN<false, __VA_ARGS__ 7>; lds = sizeof(LDS); break;   /* barriers only */
+        VRWKV_ROLE_CASES(60, wkv7v6::bwd_kernel_v6, wkv7v6::LdsV6, 0, 0, 1, false, true,)
+        VRWKV_ROLE_CASES(70, wkv7v7::bwd_kernel_v7, wkv7v7::LdsV7, 0, 0, 1,)
+        VRWKV_ROLE_CASES(80, wkv7v8::bwd_kernel_v8, wkv7v8::LdsV8, 0, 0, 1,)
+#undef VRWKV_ROLE_CASES
+        case 88: kern = &wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 8>; break;     // everything but the T chain (P wave 0 only raises its flag)
+        default: return VRWKV_EINVAL;
+    }
+    return launch_lds(kern, grid, dim3(768), lds, st, p);
+}
+
+// profiling entry: 3 = v7 with the v6 stamps; 20 + SKIP mask = the v6 profiling build with roles switched off
+inline int launch_profile(int backward, dim3 grid, hipStream_t st, const wkv7::BwdArgs& p) {
+    if (backward == 3) return launch_lds(&wkv7v7::bwd_kernel_v7<true>, grid, dim3(768), sizeof(wkv7v7::LdsV7), st, p);
+    void (*kern)(wkv7::BwdArgs) = nullptr;
+    switch (backward - 20) {
+        case 0: kern = &wkv7v6::bwd_kernel_v6<true, 0, 0, 1, false, true, 0>; break;
+        case 1: kern = &wkv7v6::bwd_kernel_v6<true, 0, 0, 1, false, true, 1>; break;
+        case 2: kern = &wkv7v6::bwd_kernel_v6<true, 0, 0, 1, false, true, 2>; break;
+        case 3: kern = &wkv7v6::bwd_kernel_v6<true, 0, 0, 1, false, true, 3>; break;
+        case 4: kern = &wkv7v6::bwd_kernel_v6<true, 0, 0, 1, false, true, 4>; break;
+        case 5: kern = &wkv7v6::bwd_kernel_v6<true, 0, 0, 1, false, true, 5>; break;
+        case 6: kern = &wkv7v6::bwd_kernel_v6<true, 0, 0, 1, false, true, 6>; break;
+        default: kern = &wkv7v6::bwd_kernel_v6<true, 0, 0, 1, false, true, 7>; break;
+    }
+    return launch_lds(kern, grid, dim3(768), sizeof(wkv7v6::LdsV6), st, p);
+}
+
+}  // namespace wkv7exp

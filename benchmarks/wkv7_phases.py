@@ -20,8 +20,11 @@ def run(B=8, T=2624, H=32, bwd_variant=-1, fwd_variant=-1):
     st = torch.cuda.current_stream().cuda_stream
     out = {}
     BWD6 = ["I_scores_dM", "I_flagwait", "I_isplit", "I_barrier", "I_top", "J_jsplit", "J_dMwait", "J_products", "J_barrier", "J_top",
-            "P_tail", "P_prep", "P_drain", "P_barrier", "P_top", "realtime_100MHz", "J_js_split", "J_js_outputs", "I_is_dSA_dR", "I_is_dV"]
+            "P_tail", "P_prep", "P_drain", "P_barrier", "P_top", "realtime_100MHz", "J_js_split", "J_js_outputs", "I_is_dSA_dR", "I_is_dV", "J_tail"]
+    only = os.environ.get("VRWKV_PHASES_ONLY")        # e.g. "4": the v8 entry alone
     for bw, names in ((0, FWD), (1, BWD5), (2, BWD6), (3, BWD6), (4, BWD6)):
+        if only is not None and str(bw) not in only.split(","):
+            continue
         dbg = torch.zeros(32, dtype=torch.int64, device=dev)
         rc = lib.vrwkv_wkv7_profile_bf16(bw, B, T, H, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), z.data_ptr(), a.data_ptr(),
                                          dy.data_ptr(), y.data_ptr(), s.data_ptr(), sa.data_ptr(), *[x.data_ptr() for x in g], dbg.data_ptr(), st)

@@ -13,11 +13,12 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 def build_emu(force=False):
     srcs = sorted(glob.glob(os.path.join(HERE, "emu_*.cpp")))
-    deps = srcs + glob.glob(os.path.join(HERE, "*.h")) + glob.glob(os.path.join(CSRC, "*.h"))
+    EXP = os.path.join(ROOT, "benchmarks", "experiments")      # A/B partners kept lane-exact too (wkv7_bwd_v7.h, the J-wave tail)
+    deps = srcs + glob.glob(os.path.join(HERE, "*.h")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(EXP, "*.h"))
     if not force and os.path.exists(SO) and all(os.path.getmtime(d) <= os.path.getmtime(SO) for d in deps):
         return SO
     cxx = CLANG if os.path.exists(CLANG) else "clang++"
-    cmd = [cxx, "-O1", "-std=c++17", "-fPIC", "-shared", "-I", HERE, "-I", CSRC, "-I", os.path.join(ROOT, "include"), *srcs, "-o", SO]
+    cmd = [cxx, "-O1", "-std=c++17", "-fPIC", "-shared", "-I", HERE, "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-I", EXP, *srcs, "-o", SO]
     subprocess.run(cmd, check=True)
     return SO
 

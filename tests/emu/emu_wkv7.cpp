@@ -6,7 +6,7 @@
 #include <wkv7_fwd_v3.h>
 #include <wkv7_fwd_v4.h>
 #include <wkv7_bwd_v6.h>
-#include <wkv7_bwd_v7.h>
+#include <wkv7_bwd_v7.h>   // benchmarks/experiments (A/B partner; kept lane-exact here)
 #include <wkv7_bwd_v8.h>
 #include <wkv7_bwd_v5.h>
 #include <wkv6_chunked.h>

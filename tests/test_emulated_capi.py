@@ -63,4 +63,7 @@ def test_argument_checks_of_the_launchers(emu_lib):
     assert f(1, 15, 1, *[P(x) for x in (w, q, k, v, z, a, y, s, sa)], None) != 0            # T % 16
     assert f(1, 16, 1, P(w), None, *[P(x) for x in (k, v, z, a, y, s, sa)], None) != 0      # null pointer
     assert emu_lib.vrwkv_wkv7_set_backward_variant(4) != 0                                   # dropped generations
+    for v in (7, 10, 11, 61, 81):                                                            # A/B partners live in benchmarks/experiments, not in the product launcher
+        assert emu_lib.vrwkv_wkv7_set_backward_variant(v) != 0
+    assert emu_lib.vrwkv_wkv7_last_variant(0) in (0, 4, 6, 7) and emu_lib.vrwkv_wkv7_last_variant(1) in (0, 5, 6, 8, 9)
     assert emu_lib.vrwkv_wkv7_set_backward_variant(-1) == 0

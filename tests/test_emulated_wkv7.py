@@ -63,7 +63,7 @@ def test_forward_from_state(emu_lib):
 def test_backward_chunked(emu_lib, mode, T):
     """Chunked MFMA backward kernels run lane-exactly on the host: 6 = the producer / consumer schedule (wkv7_bwd_v5.h), 7 = the three-stage wave pipeline (wkv7_bwd_v6.h;
     1, 2 and 6 chunks: pipeline shorter than, equal to and longer than its depth), 8 = the same pipeline with the full-row memory
-    role (wkv7_bwd_v7.h: rows by LDS-DMA, single-buffered staging and result images; 1 .. 5 chunks = only ragged steps, 10 chunks =
+    role (benchmarks/experiments/wkv7_bwd_v7.h, an A/B partner outside the library: rows by LDS-DMA, single-buffered staging and result images; 1 .. 5 chunks = only ragged steps, 10 chunks =
     five steady-state steps), 9 = wkv7_bwd_v8.h (one copy of dL/dS handed from the I to the J waves as an operand image, the decay-gradient
     term as an MFMA diagonal, the T chain on P wave 0, single-buffered S0), 10 = 9 with the score pieces a step ahead on the P waves, 11 / 12 = 9 / 10 with
     the element-wise tail and the gradient stores on the J waves (JTAIL)."""

@@ -21,7 +21,7 @@ HOST_LIB_PATH = os.path.join(PKG_DIR, "libvisualrwkv_host.so")    # the op's CPU
 HASH_PATH = LIB_PATH + ".hash"      # content hash of the sources the library was built from; travels with it
 ARCH = "gfx950"
 
-SOURCES = ["wkv7_capi.hip", "wkv7_host.hip", "probe.hip", "fused_ops.hip", "tmix_fused.hip", "attention.hip", "wkv7_step.hip", "ln_fused.hip", "wkv6_capi.hip", "loss_fused.hip", "gemv_decode.hip", "decode_fused.hip", "lora_wgrad.hip", "visual_ops.hip", "patch_embed.hip", "image_ops.hip"]
+SOURCES = ["wkv7_capi.hip", "wkv7_profile.hip", "wkv7_host.hip", "probe.hip", "fused_ops.hip", "tmix_fused.hip", "attention.hip", "wkv7_step.hip", "ln_fused.hip", "wkv6_capi.hip", "loss_fused.hip", "gemv_decode.hip", "decode_fused.hip", "lora_wgrad.hip", "visual_ops.hip", "patch_embed.hip", "image_ops.hip"]
 
 
 def hipcc() -> str:
@@ -67,13 +67,13 @@ def _stale() -> bool:
 # faster than the two scalar instructions they replace and need v_mov shuffles to form aligned register
 # pairs and cannot take DPP operands (every scan step becomes v_mov_dpp + v_pk_add).  Same-box A/B, alternating processes:
 # forward -1..2 %, backward (v5, v6) -1..2 %.
-EXTRA_FLAGS = {"attention.hip": ["-fno-honor-nans"], "wkv7_capi.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"attention.hip": ["-fno-honor-nans"], "wkv7_capi.hip": ["-fno-slp-vectorize"], "wkv7_profile.hip": ["-fno-slp-vectorize"]}
 OBJ_DIR = os.path.join(PKG_DIR, "_build")
 
 
 def _common_flags():
     return [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I", CSRC, "-I", os.path.join(REPO_DIR, "include"),
-            "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form", *os.environ.get("VRWKV_EXTRA_HIPCC_FLAGS", "").split()]
+            "-Wno-unused-result", "-Wno-inline-asm", "-mllvm", "-amdgpu-mfma-vgpr-form", *os.environ.get("VRWKV_EXTRA_HIPCC_FLAGS", "").split()]
 
 
 def _object_for(src: str, header_digest: str) -> tuple:

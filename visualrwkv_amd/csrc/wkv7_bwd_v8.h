@@ -21,7 +21,7 @@
 #pragma once
 #include <gfx950_prims.h>
 #include <wkv7_chunked.h>
-#include <wkv7_bwd_v7.h>     // ChunkImg7, RawP, DmaLane, dma_lane, prep7, dscores-style helpers; through it v6 / v5 building blocks
+#include <wkv7_bwd_rows.h>     // ChunkImg7, RawP, DmaLane, dma_lane, prep7, dscores-style helpers; through it v6 / v5 building blocks
 
 #ifndef VRWKV_V8_ROTATE
 #define VRWKV_V8_ROTATE 1
@@ -208,29 +208,34 @@ DEVFN void tail8(LdsV8& lds, int par, const TailQ& tr, const BwdArgs& p, size_t 
     *out(p.da) = make_uint2(cvt_pk_bf16(da[0], da[1]), cvt_pk_bf16(da[2], da[3]));
 }
 
-// The same tail on the J waves (JTAIL): dZt dQt dAh dKh arrive in registers (lane = token c16, 4 channels 16w + 4g ..), the operands of
+// The same tail on the J waves (JTAIL): dZt dQt dAh dKh stay in registers (lane = token c16, 4 channels 16w + 4g ..), the operands of
 // the decay-gradient integrand come from the chunk's operand images (hi + lo; this lane's own 8-byte pieces, the layout the P waves wrote),
-// log2 c_t from the ring; glast[cj & 1] was written by this wave a few instructions ago (wave_lds_fence orders the exchange).
-DEVFN void jtail8(LdsV8& lds, const ChunkImg7& B, int cj, const f32x4& dZt, const f32x4& dQt, const f32x4& dAh, const f32x4& dKh,
-                  const BwdArgs& p, size_t u, unsigned lane_boff, int c16, int w, int g, const LaneAddr& la) {
+// log2 c_t from the ring.  The tail of a chunk runs ONE STEP LATER, between the J waves' own matrix-core phase and their wait for the score
+// gradients (where they stood 0.6-0.9k cycles per step): run right after the chunk's products it lengthened the J waves' dependent chain
+// and the step by 9 % (profiles/r5a_wkv7_ab.jsonl).  The images of a chunk are overwritten in the next step, so the inputs are lifted
+// into registers (JTailIn, 36 registers with the results) at the end of the chunk's own step.
+struct JTailIn { uint2 o[8]; float4 x2; f32x4 dZt, dQt, dAh, dKh; };
+DEVFN void jtail_lift(JTailIn& t, const LdsV8& lds, const ChunkImg7& B, int cj, const f32x4& dZt, const f32x4& dQt, const f32x4& dAh, const f32x4& dKh, const LaneAddr& la) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t.o[i] = ld8(&B.opnd[i][la.own]);
+    t.x2 = *reinterpret_cast<const float4*>(&lds.x2r[cj % 3][la.f32]);
+    t.dZt = dZt; t.dQt = dQt; t.dAh = dAh; t.dKh = dKh;
+}
+DEVFN void jtail_run(const JTailIn& t, const LdsV8& lds, int cj, const BwdArgs& p, size_t u, unsigned lane_boff, int c16, int w, int g) {
     float zh[4], zl[4], qh[4], ql[4], ah[4], al[4], kh[4], kl[4];
-    unpack4(ld8(&B.opnd[0][la.own]), zh); unpack4(ld8(&B.opnd[1][la.own]), zl);
-    unpack4(ld8(&B.opnd[2][la.own]), qh); unpack4(ld8(&B.opnd[3][la.own]), ql);
-    unpack4(ld8(&B.opnd[4][la.own]), ah); unpack4(ld8(&B.opnd[5][la.own]), al);
-    unpack4(ld8(&B.opnd[6][la.own]), kh); unpack4(ld8(&B.opnd[7][la.own]), kl);
-    const float4 x4 = *reinterpret_cast<const float4*>(&lds.x2r[cj % 3][la.f32]);
-    wave_lds_fence();
-    const float4 gl4 = *reinterpret_cast<const float4*>(&lds.glast[cj & 1][16 * w + 4 * g]);
-    const float x2v[4] = {x4.x, x4.y, x4.z, x4.w}, glv[4] = {gl4.x, gl4.y, gl4.z, gl4.w};
+    unpack4(t.o[0], zh); unpack4(t.o[1], zl); unpack4(t.o[2], qh); unpack4(t.o[3], ql);
+    unpack4(t.o[4], ah); unpack4(t.o[5], al); unpack4(t.o[6], kh); unpack4(t.o[7], kl);
+    const float4 gl4 = *reinterpret_cast<const float4*>(&lds.glast[cj & 1][16 * w + 4 * g]);      // written by this wave a step ago
+    const float x2v[4] = {t.x2.x, t.x2.y, t.x2.z, t.x2.w}, glv[4] = {gl4.x, gl4.y, gl4.z, gl4.w};
     float dz[4], dq[4], da[4], dk[4], dw[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float x2 = x2v[e], l2 = x2 - dpp_shr1_fill(x2, 0.f);        // log2 w_t = the difference of log2 c_t along t
         const float cc = fast_exp2(x2), ic = fast_exp2(-x2);
         const float cp = dpp_shr1_fill(cc, 1.f);
-        dz[e] = dZt[e] * cp; dq[e] = dQt[e] * cc; da[e] = dAh[e] * ic; dk[e] = dKh[e] * ic;
+        dz[e] = t.dZt[e] * cp; dq[e] = t.dQt[e] * cc; da[e] = t.dAh[e] * ic; dk[e] = t.dKh[e] * ic;
         // dq q - da a - dk k + (dz z)(t+1) with q = Qt / c_t etc.: the decay factors cancel
-        float gt = dQt[e] * (qh[e] + ql[e]) - dAh[e] * (ah[e] + al[e]) - dKh[e] * (kh[e] + kl[e]) + dpp_shl<1>(dZt[e] * (zh[e] + zl[e]));
+        float gt = t.dQt[e] * (qh[e] + ql[e]) - t.dAh[e] * (ah[e] + al[e]) - t.dKh[e] * (kh[e] + kl[e]) + dpp_shl<1>(t.dZt[e] * (zh[e] + zl[e]));
         if (c16 == 15) gt += glv[e];
         gt += dpp_shl<1>(gt); gt += dpp_shl<2>(gt); gt += dpp_shl<4>(gt); gt += dpp_shl<8>(gt);   // suffix sum over t
         dw[e] = gt * (l2 * LN2);
@@ -563,6 +568,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
         for (int h = 0; h < 2; ++h) tro[kb][h] = img_off(32 * kb + 8 * g + 4 * h + (c16 >> 2), 16 * w + 4 * (c16 & 3));
     bf16x8 s0h_p[2] = {mk8(0u, 0u, 0u, 0u), mk8(0u, 0u, 0u, 0u)}, s0l_p[2] = {mk8(0u, 0u, 0u, 0u), mk8(0u, 0u, 0u, 0u)};   // S0 operands of the previous step = S_L of this one
     unsigned n_dm = 0;
+    JTailIn jt{};                                       // JTAIL: results and tail inputs of the chunk of the previous step
     for (int n = 0; n < nsteps; ++n) {
         const int cj = nchunk + 1 - n;
         WKV_STAMP(4)
@@ -649,6 +655,9 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                 WKV_STAMP(6)
             }
             WKV_STAMP(0)
+            // the tail of the previous step's chunk: VALU + stores beside this chunk's matrix-core phase and the wait for its score gradients
+            if (JTAIL && cj + 1 <= nchunk - 1) jtail_run(jt, lds, cj + 1, p, head_base + (size_t)(cj + 1) * L * ts, out_off * 2u, c16, w, g);
+            WKV_STAMP(7)
             // ---------------------------------------------------------------- dM products
             const bf16x8 qzh = mk8(lds_read_tr16(&B.opnd[2][la.trc]), lds_read_tr16(&B.opnd[0][la.trc]));      // [Qt^T | Zt^T]
             const bf16x8 qzl = mk8(lds_read_tr16(&B.opnd[3][la.trc]), lds_read_tr16(&B.opnd[1][la.trc]));
@@ -684,7 +693,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
             // results: lane = token c16, registers = channels 16w + 4g + e -> the fp32 image of the P waves' tail, once the tail of
             // the chunk before (this step's, steps 3 ..) has read it: 4 P waves per tail
             if (JTAIL) {
-                jtail8(lds, B, cj, dZt, dQt, dAh, dKh, p, head_base + (size_t)cj * L * ts, out_off * 2u, c16, w, g, la);
+                jtail_lift(jt, lds, B, cj, dZt, dQt, dAh, dKh, la);
             } else {
                 if (!(SKIP & 1) && n >= 3) lds_flag_wait(&lds.flag[4], 4u * (unsigned)(n - 2));
                 *reinterpret_cast<float4*>(&lds.res[0][la.f32]) = make_float4(dZt[0], dZt[1], dZt[2], dZt[3]);
@@ -697,8 +706,9 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
         block_sync_lds();
         WKV_STAMP(3)
     }
+    if (JTAIL && !(SKIP & 4)) jtail_run(jt, lds, 0, p, head_base, out_off * 2u, c16, w, g);          // the tail of chunk 0
     WKV_STAMP_FLUSH(256 + 64 * VRWKV_PROF_WAVE, 5, 5)
-    if (PROF && blockIdx.x == 0 && tid == 256 + 64 * VRWKV_PROF_WAVE) { p.dbg[16] = tacc_[5]; p.dbg[17] = tacc_[6]; }   // j-split: operand reads + split | outputs
+    if (PROF && blockIdx.x == 0 && tid == 256 + 64 * VRWKV_PROF_WAVE) { p.dbg[16] = tacc_[5]; p.dbg[17] = tacc_[6]; p.dbg[20] = tacc_[7]; }   // j-split: operand reads + split | outputs
 }
 
 }  // namespace wkv7v8

@@ -22,7 +22,7 @@
 #include <gfx950_prims.h>
 #include <wkv7_chunked.h>
 #include <wkv7_fwd_v3.h>     // SF, SplitF, splitf, regmm_pre, mm_f32_image helpers
-#include <wkv7_bwd_v7.h>     // DmaLane / dma_lane and (through it) the v5 image helpers
+#include <wkv7_bwd_rows.h>     // DmaLane / dma_lane and (through it) the v5 image helpers
 
 namespace wkv7f4 {
 
