@@ -47,8 +47,31 @@
 #ifndef VRWKV_V8_CHAINS
 #define VRWKV_V8_CHAINS 0
 #endif
+// issue-cost probe (experiment builds only): N extra scalar / vector / wait instructions per step in the J waves (role 1) or the P waves (role 2)
+#ifndef VRWKV_V8_DUMMY_N
+#define VRWKV_V8_DUMMY_N 0
+#endif
+#ifndef VRWKV_V8_DUMMY_KIND
+#define VRWKV_V8_DUMMY_KIND 0       // 0: s_mov_b32   1: v_mov_b32   2: s_nop 0
+#endif
+#ifndef VRWKV_V8_DUMMY_ROLE
+#define VRWKV_V8_DUMMY_ROLE 1
+#endif
 
 namespace wkv7v8 {
+
+template <int ROLE>
+DEVFN void dummy_issue() {
+#if VRWKV_V8_DUMMY_N > 0
+    if (ROLE != VRWKV_V8_DUMMY_ROLE) return;
+#pragma unroll
+    for (int i = 0; i < VRWKV_V8_DUMMY_N; ++i) {
+        if (VRWKV_V8_DUMMY_KIND == 0) { unsigned t; asm volatile("s_mov_b32 %0, 0" : "=s"(t)); }
+        else if (VRWKV_V8_DUMMY_KIND == 1) { unsigned t; asm volatile("v_mov_b32 %0, 0" : "=v"(t)); }
+        else asm volatile("s_nop 0");
+    }
+#endif
+}
 
 using wkv7::BwdArgs;
 using namespace wkv7c;
@@ -313,6 +336,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
             const int cp = nchunk - 1 - n, cd = cp + 1, ct = cp + 3;      // images | the I waves' chunk: T now, S0 for the J waves' next step | tail
             WKV_STAMP(4)
             if (!(SKIP & 1)) {
+                dummy_issue<2>();
                 RawP raw;
                 const bool do_prep = FULL || cp >= 0;
                 if (do_prep) {
@@ -577,6 +601,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
             lds_flag_add(&lds.flag[0]);
         }
         if (!(SKIP & 4) && cj >= 0 && cj <= nchunk - 1) {
+            dummy_issue<1>();
             const ChunkImg7& B = lds.b[cj % 3];
             const uint16_t* drh = lds.dr[cj & 1][0];
             const uint16_t* drl = lds.dr[cj & 1][1];
