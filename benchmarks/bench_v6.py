@@ -71,16 +71,30 @@ def main():
         loss = step()
         losses.append(round(float(loss.detach()), 3))
     torch.cuda.synchronize()
+    from visualrwkv_amd import wkv6
+    wkv6.EVENT_LOG = []              # HIP events on the launch stream around every WKV6 launch of the timed steps
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
         losses.append(loss.detach())
     torch.cuda.synchronize()
+    log, wkv6.EVENT_LOG = wkv6.EVENT_LOG, None
     losses = [float(x) if torch.is_tensor(x) else x for x in losses]
     dt = (time.perf_counter() - t0) / a.steps
     T = T_text + 577
     n_par = sum(p.numel() for p in model.rwkv.parameters())
-    print(json.dumps({"config": "cfg4: VisualRWKV-6 %dL C%d + CLIP ViT-L/14-336" % (a.layers, C), "lm_params_B": round(n_par / 1e9, 2),
+    # in-step WKV6 kernels against the 8 TB/s roofline, bytes as benchmarks/wkv6_micro.py counts them (r,k,v bf16 + ew f32 + y, plus the
+    # 16 B / element chunk-state checkpoint this implementation writes in the forward and reads in the backward)
+    FWD_B, BWD_B = 2 * 3 + 4 + 2 + 16, 2 * 4 + 4 + 16 + 2 * 4
+    wkv = {}
+    for kind, bpe in (("fwd", FWD_B), ("bwd", BWD_B)):
+        ms = [e0.elapsed_time(e1) for k_, e0, e1, _ in log if k_ == kind]
+        if ms:
+            elems = next(n for k_, _, _, n in log if k_ == kind)
+            avg = sum(ms) / len(ms)
+            wkv[kind] = {"avg_ms": round(avg, 4), "launches": len(ms), "bytes_per_elem": bpe, "achieved_GBps": round(elems * bpe / (avg * 1e-3) / 1e9, 1),
+                         "frac_of_8TBps": round(elems * bpe / (avg * 1e-3) / 8e12, 4)}
+    print(json.dumps({"config": "cfg4: VisualRWKV-6 %dL C%d + CLIP ViT-L/14-336" % (a.layers, C), "wkv6_in_step": wkv, "lm_params_B": round(n_par / 1e9, 2),
                       "micro_bsz": B, "seq_len": T, "tokens_per_s": round(B * T / dt), "ms_per_step": round(dt * 1e3, 1),
                       "losses": [round(x, 3) for x in losses], "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1), "grad_cp": a.grad_cp, "fused": bool(a.fused)}))
 

@@ -402,6 +402,54 @@ class _ReluSq(torch.autograd.Function):
         return dh
 
 
+class _ReluSqLinear(torch.autograd.Function):
+    """value(relu(h)^2) of the channel-mix (src/model.py:225-226) WITHOUT keeping relu(h)^2 for the backward: 4 of the ~40 activation
+    tensors a layer keeps (it is as wide as the FFN).  The backward forms it again from h (one streaming kernel, 0.21 ms per layer at
+    micro-batch 16) for the weight gradient.  Selective recompute (`grad_cp=1`) only; gradients are those of relu_sq + _LinearTN."""
+
+    @staticmethod
+    def forward(ctx, h, w):
+        h = h.contiguous()
+        _chk(h)
+        y = torch.empty_like(h)
+        hip_lib.check(hip_lib.load().vrwkv_relusq_fwd_bf16(h.numel(), h.data_ptr(), y.data_ptr(), _stream(h)), "vrwkv_relusq_fwd_bf16")
+        ctx.save_for_backward(h, w)
+        ctx.wparam = w if hasattr(w, "_vrwkv_flat_grad") else None
+        return F.linear(y, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, w = ctx.saved_tensors
+        lib = hip_lib.load()
+        y = torch.empty_like(h)
+        hip_lib.check(lib.vrwkv_relusq_fwd_bf16(h.numel(), h.data_ptr(), y.data_ptr(), _stream(h)), "vrwkv_relusq_fwd_bf16")
+        dy = dy.contiguous()
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dy2, y2 = dy.reshape(-1, dy.shape[-1]), y.reshape(-1, y.shape[-1])
+            wp = ctx.wparam
+            if (FLAT_WGRAD and wp is not None and wp.grad is None and getattr(wp, "_vrwkv_flat_armed", False)
+                    and not getattr(wp, "_vrwkv_wgrad_pending", False) and wp._vrwkv_flat_grad[0].dtype == dy.dtype):
+                flat, o = wp._vrwkv_flat_grad                # as _LinearTN: straight into the ZeRO-1 engine's flat gradient buffer
+                dw = flat[o:o + wp.numel()].view(wp.shape)
+                if wgrad_big_supported(dy2, y2) and o % 8 == 0:
+                    wgrad_big(dy2, y2, out=dw)
+                else:
+                    torch.mm(dy2.t(), y2, out=dw)
+                wp._vrwkv_wgrad_pending = True
+            elif wgrad_big_supported(dy2, y2):
+                dw = wgrad_big(dy2, y2)
+            else:
+                dw = dy2.t().mm(y2)
+        dh = None
+        if ctx.needs_input_grad[0]:
+            dyy = F.linear(dy, transpose2d(w))               # gradient of relu(h)^2, into the buffer the recompute used
+            del y
+            dh = torch.empty_like(h)
+            hip_lib.check(lib.vrwkv_relusq_bwd_bf16(h.numel(), h.data_ptr(), dyy.data_ptr(), dh.data_ptr(), _stream(h)), "vrwkv_relusq_bwd_bf16")
+        return dh, dw
+
+
 mix = _Mix.apply
 mix_dup3 = _MixDup3.apply
 decay = _Decay.apply
@@ -582,21 +630,34 @@ def _block_segment(block, x, delta, v_first):
     return x, ffn(h), v_first
 
 
-def blocks_forward(rwkv, x, grad_cp=False):
+def blocks_forward(rwkv, x, grad_cp=0):
     """All Blocks + ln_out with the residual adds fused into the LayerNorms (same math as Block.forward chained,
-    src/model.py:247-254,313-318): the residual stream is carried as (x, pending delta).  grad_cp: every Block is
-    re-computed in the backward (the reference's default recipe, deepspeed.checkpointing.checkpoint per block,
-    src/model.py:318-319) -- through these same fused kernels, so the recompute and the backward use add_ln / the glue
-    kernels / the WKV7 op, not the eager modules."""
+    src/model.py:247-254,313-318): the residual stream is carried as (x, pending delta).
+    grad_cp (the reference's memory-saving switch, src/model.py:318-319: deepspeed.checkpointing.checkpoint per block):
+      0  keep every activation (288 GB of HBM hold the 1.5B model at micro-batch 16: 192 GB);
+      1  SELECTIVE recompute: keep what is expensive to recompute (every GEMM output), drop what is cheap to recompute and large -- the WKV7
+         chunk checkpoints `s` and `sa` (10 of the ~40 activation tensors of a layer: the backward re-runs the forward kernel) and relu(h)^2 of
+         the channel-mix (4 of them: one streaming kernel) -- about a third of the activation memory for ~1 ms per layer;
+      2  the reference's recipe: every Block re-computed in the backward -- through these same fused kernels, so the recompute and the
+         backward use add_ln / the glue kernels / the WKV7 op, not the eager modules."""
+    global SELECTIVE_RECOMPUTE
+    from . import wkv7
+    grad_cp = int(grad_cp)
     x = rwkv.blocks[0].ln0(x)
     v_first = torch.empty_like(x)
     delta = None
-    for block in rwkv.blocks:
-        if grad_cp:
-            from torch.utils.checkpoint import checkpoint
-            x, delta, v_first = checkpoint(_block_segment, block, x, delta, v_first, use_reentrant=False)
-        else:
-            x, delta, v_first = _block_segment(block, x, delta, v_first)
+    prev = SELECTIVE_RECOMPUTE
+    SELECTIVE_RECOMPUTE = grad_cp == 1 and torch.is_grad_enabled()
+    try:
+        with wkv7.recompute_state(SELECTIVE_RECOMPUTE):
+            for block in rwkv.blocks:
+                if grad_cp >= 2:
+                    from torch.utils.checkpoint import checkpoint
+                    x, delta, v_first = checkpoint(_block_segment, block, x, delta, v_first, use_reentrant=False)
+                else:
+                    x, delta, v_first = _block_segment(block, x, delta, v_first)
+    finally:
+        SELECTIVE_RECOMPUTE = prev
     _, h = add_ln(x, delta, rwkv.ln_out)
     return h
 
@@ -873,8 +934,15 @@ def cmix_forward(m, x):
     return cmix_from_mixed(m, k)
 
 
+SELECTIVE_RECOMPUTE = False        # set by blocks_forward(grad_cp=1) around the block stack: see _ReluSqLinear, wkv7.RECOMPUTE_STATE
+
+
 def cmix_from_mixed(m, k):
-    return linear(m.value, relu_sq(linear(m.key, k)))
+    h = linear(m.key, k)
+    if (SELECTIVE_RECOMPUTE and DGRAD_TN and m.value.bias is None and h.is_cuda and h.dtype == torch.bfloat16 and torch.is_grad_enabled()
+            and h.requires_grad):
+        return _ReluSqLinear.apply(h, m.value.weight)
+    return linear(m.value, relu_sq(h))
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -266,8 +266,10 @@ class RWKV(nn.Module):
     """Embedding -> n_layer Blocks -> ln_out -> head, on already-embedded inputs (src/model.py:273-325).
 
     `forward(x_emb)` left-pads T to a multiple of CHUNK_LEN with emb(STOP_TOKEN_INDEX) and strips the
-    pad from the logits.  `args.grad_cp == 1` re-computes each Block in the backward (the reference
-    uses deepspeed.checkpointing.checkpoint; here torch.utils.checkpoint -- same schedule)."""
+    pad from the logits.  `args.grad_cp` is the reference's memory-saving switch (src/model.py:318-319: deepspeed.checkpointing.checkpoint per
+    Block).  Eager path: >= 1 re-computes each Block in the backward (torch.utils.checkpoint -- same schedule).  Fused path
+    (fused.blocks_forward): 1 = selective recompute (WKV7 checkpoints + relu^2 dropped, every GEMM output kept: a third of the activation memory for
+    ~4 % of the step), 2 = every Block re-computed as the reference does."""
 
     def __init__(self, args):
         super().__init__()
@@ -299,10 +301,10 @@ class RWKV(nn.Module):
         if getattr(args, "fused", False):
             from . import fused
             if fused.add_ln_supported(x):
-                return fused.blocks_forward(self, x, grad_cp=args.grad_cp == 1 and torch.is_grad_enabled()), num_tokens_to_pad
+                return fused.blocks_forward(self, x, grad_cp=int(args.grad_cp) if torch.is_grad_enabled() else 0), num_tokens_to_pad
         v_first = torch.empty_like(x)
         for block in self.blocks:
-            if args.grad_cp == 1 and torch.is_grad_enabled():
+            if args.grad_cp >= 1 and torch.is_grad_enabled():
                 from torch.utils.checkpoint import checkpoint
                 x, v_first = checkpoint(block, x, v_first, use_reentrant=False)
             else:

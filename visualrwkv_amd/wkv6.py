@@ -41,6 +41,23 @@ def ckpt_tensor(B, T, H, device):
     return torch.empty(n, dtype=torch.float32, device=device)
 
 
+# Optional per-launch timing with HIP events on the launch stream (benchmarks/bench_v6.py's roofline leg), as wkv7.EVENT_LOG: when it is a
+# list, every launch appends (kind, start_event, end_event, B*T*C).
+EVENT_LOG = None
+
+
+def _timed(kind, elems, dev, fn):
+    if EVENT_LOG is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st = torch.cuda.current_stream(dev)
+    e0.record(st)
+    rc = fn()
+    e1.record(st)
+    EVENT_LOG.append((kind, e0, e1, elems))
+    return rc
+
+
 def forward_hip(B, T, C, H, r, k, v, ew, u, y, ckpt=None):
     """ew is the f32 log decay the reference's kernels take (`w` of wkv6_op.cpp:8)."""
     bf = torch.bfloat16
@@ -51,9 +68,8 @@ def forward_hip(B, T, C, H, r, k, v, ew, u, y, ckpt=None):
         raise ValueError(f"wkv6: u must have {C} elements")
     _chk("u", u, u.shape, bf)
     with torch.cuda.device(r.device):
-        rc = hip_lib.load().vrwkv_wkv6_forward_bf16(B, T, C, H, r.data_ptr(), k.data_ptr(), v.data_ptr(), ew.data_ptr(),
-                                                    u.data_ptr(), y.data_ptr(), ckpt.data_ptr() if ckpt is not None else 0,
-                                                    _stream(r))
+        rc = _timed("fwd", B * T * C, r.device, lambda: hip_lib.load().vrwkv_wkv6_forward_bf16(
+            B, T, C, H, r.data_ptr(), k.data_ptr(), v.data_ptr(), ew.data_ptr(), u.data_ptr(), y.data_ptr(), ckpt.data_ptr() if ckpt is not None else 0, _stream(r)))
     hip_lib.check(rc, "vrwkv_wkv6_forward_bf16")
 
 
@@ -68,9 +84,9 @@ def backward_hip(B, T, C, H, r, k, v, ew, u, gy, gr, gk, gv, gw, gu, ckpt=None):
         ckpt = ckpt_tensor(B, T, H, r.device)
         forward_hip(B, T, C, H, r, k, v, ew, u, torch.empty_like(r), ckpt)
     with torch.cuda.device(r.device):
-        rc = hip_lib.load().vrwkv_wkv6_backward_bf16(B, T, C, H, r.data_ptr(), k.data_ptr(), v.data_ptr(), ew.data_ptr(),
-                                                     u.data_ptr(), gy.data_ptr(), ckpt.data_ptr(), gr.data_ptr(),
-                                                     gk.data_ptr(), gv.data_ptr(), gw.data_ptr(), gu.data_ptr(), _stream(r))
+        rc = _timed("bwd", B * T * C, r.device, lambda: hip_lib.load().vrwkv_wkv6_backward_bf16(
+            B, T, C, H, r.data_ptr(), k.data_ptr(), v.data_ptr(), ew.data_ptr(), u.data_ptr(), gy.data_ptr(), ckpt.data_ptr(), gr.data_ptr(),
+            gk.data_ptr(), gv.data_ptr(), gw.data_ptr(), gu.data_ptr(), _stream(r)))
     hip_lib.check(rc, "vrwkv_wkv6_backward_bf16")
 
 

@@ -193,6 +193,28 @@ _LIB = _register()
 _apply_variant_env()
 
 
+# Selective activation recompute (`--grad_cp 1` of the fused path, fused.blocks_forward): while this is True a training forward keeps
+# neither the chunk checkpoints `s` (16 B / element) nor `sa` (4 B / element) -- 10 of the ~40 activation tensors a 1.5B layer keeps --
+# and the backward re-runs the forward kernel to get them back (0.59 ms per layer at micro-batch 16).  The forward itself then runs
+# the entry without by-products (2 instead of 24 output bytes per element).
+RECOMPUTE_STATE = False
+
+
+class recompute_state:
+    """with wkv7.recompute_state(True): ... -- scoped switch of RECOMPUTE_STATE."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global RECOMPUTE_STATE
+        self.prev, RECOMPUTE_STATE = RECOMPUTE_STATE, self.on
+
+    def __exit__(self, *exc):
+        global RECOMPUTE_STATE
+        RECOMPUTE_STATE = self.prev
+
+
 class WindBackstepping(torch.autograd.Function):
     """src/model.py:45-65 (same asserts, same saved tensors, same allocation pattern)."""
 
@@ -204,6 +226,11 @@ class WindBackstepping(torch.autograd.Function):
         assert all(i.dtype == torch.bfloat16 or (i.dtype == torch.float32 and not i.is_cuda) for i in [w, q, k, v, z, b])
         assert all(i.is_contiguous() for i in [w, q, k, v, z, b])
         P = tparallel_segments(B, H, T, forward=True) if TPARALLEL_BWD and w.is_cuda else 1
+        ctx.recompute = bool(RECOMPUTE_STATE and w.is_cuda and w.dtype == torch.bfloat16 and P == 1)
+        if ctx.recompute:                               # y only; the backward regenerates s and sa
+            y, _ = wkv7_forward_state(w, q, k, v, z, b, None, want_state=False)
+            ctx.save_for_backward(w, q, k, v, z, b)
+            return y
         if P > 1:                                       # one long sequence: sequence-parallel forward
             y, _, s, sa = wkv7_forward_tparallel(w, q, k, v, z, b, segments=P, train=True)
         else:
@@ -216,7 +243,14 @@ class WindBackstepping(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        w, q, k, v, z, b, s, sa = ctx.saved_tensors
+        if ctx.recompute:
+            w, q, k, v, z, b = ctx.saved_tensors
+            B, T, H, C = w.shape
+            s = torch.empty(B, H, T // CHUNK_LEN, C, C, dtype=torch.float32, device=w.device)
+            sa = torch.empty(B, T, H, C, dtype=torch.float32, device=w.device)
+            torch.ops.wind_backstepping.forward(w, q, k, v, z, b, torch.empty_like(v), s, sa)
+        else:
+            w, q, k, v, z, b, s, sa = ctx.saved_tensors
         assert all(i.dtype == w.dtype for i in [dy])
         assert all(i.is_contiguous() for i in [dy])
         if TPARALLEL_BWD and w.is_cuda:                 # few heads -> sequence-parallel backward
