@@ -438,6 +438,7 @@ def main():
                 rec = json.load(open(pmc)).get(f"bwd_B{a.micro_bsz}_T{a.ctx_len}_H{args.n_embd // 64}")
                 if rec:                                    # NOT measured in this run: the committed rocprofv3 PMC passes
                     out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_kernel"] = rec.get("kernel")       # the kernel the counters were collected on (must be the one named in "kernel")
                     out["roofline"]["traffic_source"] = "profiles/wkv7_pmc.json (separate rocprofv3 --pmc passes of benchmarks/wkv7_pmc.sh, same shape)"
         if world == 1 and not a.no_cpu_baseline and not cpu_mode:
             out["cpu_baseline"] = cpu_baseline(args.n_embd, a.ctx_len)
