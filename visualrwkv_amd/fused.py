@@ -124,12 +124,33 @@ def wgrad_big(dy2d, x2d, out=None):
     return out
 
 
+def _weight_grad(wp, dy2, x2):
+    """dW = dy2^T x2 (N,K) for a Linear weight; `wp` = the Parameter when a ZeRO-1 engine (dp.Zero1Engine) armed by its zero_grad() owns
+    its gradient slot, else None.  First gradient of an armed weight in the step: the GEMM writes into the weight's slot of the flat
+    gradient buffer; autograd adopts the returned view as `.grad` and the engine finds it in place.  `pending` until the engine's hook has
+    seen it: a second use of the same weight in one graph (two forward passes under one backward) must not write the slot again while
+    autograd still holds the first gradient there."""
+    if (FLAT_WGRAD and wp is not None and wp.grad is None and getattr(wp, "_vrwkv_flat_armed", False)
+            and not getattr(wp, "_vrwkv_wgrad_pending", False) and wp._vrwkv_flat_grad[0].dtype == dy2.dtype):
+        flat, o = wp._vrwkv_flat_grad
+        dw = flat[o:o + wp.numel()].view(wp.shape)
+        if wgrad_big_supported(dy2, x2) and o % 8 == 0:
+            wgrad_big(dy2, x2, out=dw)
+        else:
+            torch.mm(dy2.t(), x2, out=dw)
+        wp._vrwkv_wgrad_pending = True
+        return dw
+    if wgrad_big_supported(dy2, x2):
+        return wgrad_big(dy2, x2)
+    return dy2.t().mm(x2)
+
+
 class _LinearTN(torch.autograd.Function):
     """F.linear(x, W) whose input gradient is issued in the layout of the forward GEMMs.  Autograd computes dx = dy.mm(W)
     with W (N_out, K_in) row-major: the contraction index is the strided one of W (hipBLASLt "N,N"), 8-15 % slower on
     MI355X than the "T,N" kernels the forward gets (both operands contraction-contiguous; measured 908 vs 1229 TFLOP/s at
     41 984 x 2048 x 2048, benchmarks/dgrad_layout_micro.py).  Here dx = F.linear(dy, W^T) on a transposed copy of the
-    weight (31-77 us per weight, included in the measurement): the same T,N kernels as the forward.  dW as autograd."""
+    weight (31-77 us per weight, included in the measurement): the same T,N kernels as the forward.  dW: _weight_grad."""
 
     @staticmethod
     def forward(ctx, x, w):
@@ -144,26 +165,7 @@ class _LinearTN(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = F.linear(dy, transpose2d(w))
         if ctx.needs_input_grad[1]:
-            dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
-            wp = ctx.wparam
-            if (FLAT_WGRAD and wp is not None and wp.grad is None and getattr(wp, "_vrwkv_flat_armed", False)
-                    and not getattr(wp, "_vrwkv_wgrad_pending", False)
-                    and wp._vrwkv_flat_grad[0].dtype == dy.dtype):
-                # ZeRO-1 engine (dp.Zero1Engine) armed by its zero_grad(), first gradient of this weight in the step: the GEMM writes into the weight's
-                # slot of the flat gradient buffer; autograd adopts the returned view as `.grad` and the engine finds it in place.
-                # `pending` until the engine's hook has seen it: a second use of the same weight in one graph (two forward passes
-                # under one backward) must not write the slot again while autograd still holds the first gradient there.
-                flat, o = wp._vrwkv_flat_grad
-                dw = flat[o:o + wp.numel()].view(wp.shape)
-                if wgrad_big_supported(dy2, x2) and o % 8 == 0:
-                    wgrad_big(dy2, x2, out=dw)
-                else:
-                    torch.mm(dy2.t(), x2, out=dw)
-                wp._vrwkv_wgrad_pending = True
-            elif wgrad_big_supported(dy2, x2):
-                dw = wgrad_big(dy2, x2)
-            else:
-                dw = dy2.t().mm(x2)
+            dw = _weight_grad(ctx.wparam, dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1]))
         return dx, dw
 
 
@@ -424,27 +426,11 @@ class _ReluSqLinear(torch.autograd.Function):
         y = torch.empty_like(h)
         hip_lib.check(lib.vrwkv_relusq_fwd_bf16(h.numel(), h.data_ptr(), y.data_ptr(), _stream(h)), "vrwkv_relusq_fwd_bf16")
         dy = dy.contiguous()
-        dw = None
-        if ctx.needs_input_grad[1]:
-            dy2, y2 = dy.reshape(-1, dy.shape[-1]), y.reshape(-1, y.shape[-1])
-            wp = ctx.wparam
-            if (FLAT_WGRAD and wp is not None and wp.grad is None and getattr(wp, "_vrwkv_flat_armed", False)
-                    and not getattr(wp, "_vrwkv_wgrad_pending", False) and wp._vrwkv_flat_grad[0].dtype == dy.dtype):
-                flat, o = wp._vrwkv_flat_grad                # as _LinearTN: straight into the ZeRO-1 engine's flat gradient buffer
-                dw = flat[o:o + wp.numel()].view(wp.shape)
-                if wgrad_big_supported(dy2, y2) and o % 8 == 0:
-                    wgrad_big(dy2, y2, out=dw)
-                else:
-                    torch.mm(dy2.t(), y2, out=dw)
-                wp._vrwkv_wgrad_pending = True
-            elif wgrad_big_supported(dy2, y2):
-                dw = wgrad_big(dy2, y2)
-            else:
-                dw = dy2.t().mm(y2)
+        dw = _weight_grad(ctx.wparam, dy.reshape(-1, dy.shape[-1]), y.reshape(-1, y.shape[-1])) if ctx.needs_input_grad[1] else None
+        del y                                                # the recomputed relu(h)^2 is only needed by the weight gradient
         dh = None
         if ctx.needs_input_grad[0]:
-            dyy = F.linear(dy, transpose2d(w))               # gradient of relu(h)^2, into the buffer the recompute used
-            del y
+            dyy = F.linear(dy, transpose2d(w))               # gradient of relu(h)^2 (the allocator hands it the bytes just freed)
             dh = torch.empty_like(h)
             hip_lib.check(lib.vrwkv_relusq_bwd_bf16(h.numel(), h.data_ptr(), dyy.data_ptr(), dh.data_ptr(), _stream(h)), "vrwkv_relusq_bwd_bf16")
         return dh, dw
