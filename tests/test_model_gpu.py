@@ -200,6 +200,13 @@ def test_full_visual_step_matches_an_independent_fp32_cpu_evaluation(monkeypatch
         print("[parity] e2e largest |scale - 1| of a gradient group:", sorted(((abs(b), n) for n, b in bias.items()), reverse=True)[:5])
     assert all(e < 2.6e-2 for e in errs.values()), worst     # observed: worst 2.1e-2 (a token-shift mix parameter); bf16 path vs fp32
     assert checked >= 30
+    # the common-mode part of that bias (the bf16 d(loss)/d(logits) every gradient descends from) is the same factor in EVERY group, so a
+    # group is also held against the others: its scale may differ from the median scale of all groups by 2.5e-3 (observed on MI355X: groups
+    # between -0.4e-3 and -3.1e-3 around a median of -2.0e-3, i.e. deviations up to 1.6e-3) -- a 0.5 % error in ONE group fails here
+    # although it passes the absolute bound above
+    med = sorted(bias.values())[len(bias) // 2]
+    off = {n: b - med for n, b in bias.items() if abs(b - med) >= 2.5e-3}
+    assert not off, (med, off)
     # ---- one optimizer step on both sides (CPU: torch AdamW + clip_grad_norm_; GPU: ZeRO-1 engine, HIP AdamW with the clip
     # factor formed on the device), then the loss again
     train = [p for p in ref.parameters() if p.requires_grad]
