@@ -6,6 +6,7 @@
 #include "hip_emu.h"
 
 #define DEVFN static inline
+#define KERNEL_MIN_WAVES(n)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -58,8 +58,12 @@ template <int D, int QT, int S> struct Geo {
     static constexpr int LDS_BYTES = K_BYTES + V_BYTES + TAB_BYTES;
 };
 
+// Registers are capped at 168 (three waves per SIMD instead of two) where that pays: QT = 2 at D = 72 (196 -> 168 VGPRs, 11 spilled outside the
+// key loop: SigLIP 0.1655 -> 0.154 ms) and SAM's global blocks with the rel-pos bias (1.31 -> 1.27 ms); the windowed rel-pos instantiation
+// spills inside its loop under the cap (+25 %) and D = 64 plain already runs three waves (profiles/r5_attention_occupancy.txt).
+constexpr int min_waves_per_simd(int D, int QT, int S) { return (QT == 2 && ((D == 72 && S == 0) || S == KT)) ? 3 : 1; }
 template <int D, int QT, int S>
-__global__ __launch_bounds__(256) void fwd_kernel(Args p) {
+__global__ __launch_bounds__(256) KERNEL_MIN_WAVES(min_waves_per_simd(D, QT, S)) void fwd_kernel(Args p) {
     using G = Geo<D, QT, S>;
     constexpr int DP = G::DP, NKB = G::NKB, DT = G::DT, KS = G::KS, VS = G::VS, SP = G::SP;
     static_assert(DT * 16 <= VS, "V row too short");

@@ -9,6 +9,8 @@
 #include <stdint.h>
 
 #define DEVFN __device__ __forceinline__
+// kernel attribute: keep the register count low enough for at least n waves per SIMD (the host emulator's gfx950_prims.h defines it away)
+#define KERNEL_MIN_WAVES(n) __attribute__((amdgpu_waves_per_eu(n)))
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
