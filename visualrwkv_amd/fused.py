@@ -423,11 +423,13 @@ class _ReluSqLinear(torch.autograd.Function):
     def backward(ctx, dy):
         h, w = ctx.saved_tensors
         lib = hip_lib.load()
-        y = torch.empty_like(h)
-        hip_lib.check(lib.vrwkv_relusq_fwd_bf16(h.numel(), h.data_ptr(), y.data_ptr(), _stream(h)), "vrwkv_relusq_fwd_bf16")
         dy = dy.contiguous()
-        dw = _weight_grad(ctx.wparam, dy.reshape(-1, dy.shape[-1]), y.reshape(-1, y.shape[-1])) if ctx.needs_input_grad[1] else None
-        del y                                                # the recomputed relu(h)^2 is only needed by the weight gradient
+        dw = None
+        if ctx.needs_input_grad[1]:                          # relu(h)^2 again, only for the weight gradient
+            y = torch.empty_like(h)
+            hip_lib.check(lib.vrwkv_relusq_fwd_bf16(h.numel(), h.data_ptr(), y.data_ptr(), _stream(h)), "vrwkv_relusq_fwd_bf16")
+            dw = _weight_grad(ctx.wparam, dy.reshape(-1, dy.shape[-1]), y.reshape(-1, y.shape[-1]))
+            del y
         dh = None
         if ctx.needs_input_grad[0]:
             dyy = F.linear(dy, transpose2d(w))               # gradient of relu(h)^2 (the allocator hands it the bytes just freed)
