@@ -210,14 +210,16 @@ def cpu_baseline(n_embd, T):
                       f"runs after 1 warm-up, {t:.2f} s per block, scaled x24; head/loss/ViT/optimizer not included"}
 
 
-def _wkv7_kernel_name(backward: int) -> str:
-    """The kernel the last WKV7 launch of this process resolved to (vrwkv_wkv7_last_variant): what the roofline entry is about."""
+def _wkv7_kernel_name(backward: int, B: int, T: int, H: int) -> str:
+    """The kernel a WKV7 launch of this shape resolves to (vrwkv_wkv7_resolve_variant: a pure function of the shape and the A/B override --
+    the launches themselves come from two threads, the Python thread and autograd's): what the roofline entry is about.
+    backward: 0 = training forward, 1 = backward, 2 = the by-product-free forward of the selective-recompute mode."""
     from visualrwkv_amd import hip_lib
-    v = hip_lib.load().vrwkv_wkv7_last_variant(backward)
+    v = hip_lib.load().vrwkv_wkv7_resolve_variant(backward, B, T, H)
     names = ({5: "wkv7v5::bwd_kernel_v5", 6: "wkv7v6::bwd_kernel_v6", 7: "wkv7v7::bwd_kernel_v7 (experiment)", 8: "wkv7v8::bwd_kernel_v8", 9: "wkv7v8::bwd_kernel_v8<AHEAD>",
-              10: "wkv7v8::bwd_kernel_v8<AHEAD,JTAIL> (experiment)", 11: "wkv7v8::bwd_kernel_v8<JTAIL> (experiment)"} if backward else
+              10: "wkv7v8::bwd_kernel_v8<AHEAD,JTAIL> (experiment)", 11: "wkv7v8::bwd_kernel_v8<JTAIL> (experiment)"} if backward == 1 else
              {7: "wkv7f4::fwd_kernel_v4", 6: "wkv7c::fwd_kernel_v3<two workgroups per head>"})
-    return names.get(v, f"wkv7c::fwd_kernel_v3<variant {v}>" if not backward else f"backward variant {v}")
+    return names.get(v, f"wkv7c::fwd_kernel_v3<variant {v}>" if backward != 1 else f"backward variant {v}")
 
 
 def main():
@@ -360,6 +362,8 @@ def main():
             f.write(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=400, max_name_column_width=50,
                                                                        max_shapes_column_width=90))
     wkv7.EVENT_LOG = [] if rank == 0 else None
+    if engine.collective and engine.overlap:
+        engine.comm_timing = []                     # exposed-communication estimate from stream events (dp.Zero1Engine.comm_report)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
@@ -372,12 +376,15 @@ def main():
     dt = float(tmax)
     tokens = world * a.micro_bsz * a.ctx_len * a.steps
 
-    # the reference's shipped recipe saves activation memory by re-computing in the backward (grad_cp=1, src/model.py:318-319); the
-    # headline keeps all activations in the 288 GB of HBM (grad_cp=0).  Same model, same batch, more timed steps in the two memory-saving
-    # modes of the fused path so that their cost is visible beside the headline (not part of `value`): 1 = selective recompute (WKV7
-    # checkpoints and relu^2 re-formed in the backward, every GEMM output kept), 2 = every block re-computed (what the reference does).
+    # The reference's shipped scripts pass `--grad_cp 1` (scripts/train/*.sh): every Block re-computed in the backward (src/model.py:318-319);
+    # BASELINE.json's config does not name grad_cp and the headline keeps all activations in the 288 GB of HBM (grad_cp=0).  Same model, same
+    # batch, 10 timed steps each in the two memory-saving modes so that their cost stands beside the headline (not part of `value`):
+    #   grad_cp 1 = the reference's recipe (block inputs only are kept), grad_cp 2 = selective recompute (WKV7 checkpoints and relu^2 re-formed
+    #   in the backward, every GEMM output kept; not in the reference).
     peak_headline = torch.cuda.max_memory_allocated() / 2**30 if dev.type == "cuda" else 0.0
-    cp1 = cp2 = None
+    comm = engine.comm_report(a.steps) if engine.comm_timing else None
+    engine.comm_timing = None
+    cp_ref = cp_sel = None
     if a.grad_cp == 0 and not a.no_grad_cp_companion and not cpu_mode:
         def companion(mode, n):
             args.grad_cp = mode
@@ -391,12 +398,12 @@ def main():
             if world > 1:
                 dist.all_reduce(tcp, op=dist.ReduceOp.MAX)
             args.grad_cp = 0
-            return {"tokens_per_s": world * a.micro_bsz * a.ctx_len * n / float(tcp), "ms_per_step": float(tcp) / n * 1e3, "steps": n,
+            return {"grad_cp": mode, "tokens_per_s": world * a.micro_bsz * a.ctx_len * n / float(tcp), "ms_per_step": float(tcp) / n * 1e3, "steps": n,
                     "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1)}
-        cp1 = companion(1, 10)
-        cp1["what"] = "selective recompute: WKV7 checkpoints (s, sa) and relu(h)^2 re-formed in the backward, every GEMM output kept"
-        cp2 = companion(2, 2)
-        cp2["what"] = "every block re-computed in the backward (the reference's deepspeed.checkpointing per block)"
+        cp_sel = companion(2, 10)
+        cp_sel["what"] = "selective recompute (not in the reference): WKV7 checkpoints (s, sa) and relu(h)^2 re-formed in the backward, every GEMM output kept"
+        cp_ref = companion(1, 10)
+        cp_ref["what"] = "the reference's --grad_cp 1 (every shipped script): every block re-computed in the backward (deepspeed.checkpointing per block)"
 
     if rank == 0:
         out = {
@@ -410,7 +417,12 @@ def main():
                        "grad_cp": a.grad_cp, "fused_elementwise": bool(args.fused), "loss": float(loss.detach()),
                        "micro_bsz": a.micro_bsz, "peak_mem_GB": None if cpu_mode else round(peak_headline, 1),
                        "gemm_kernels": f"TunableOp file, {n_tuned} shapes" if n_tuned else "library default",
-                       "grad_cp1_same_run": cp1, "grad_cp2_same_run": cp2},
+                       "grad_cp_meaning": "0 keep all activations (headline) | 1 = the reference's --grad_cp 1: every block re-computed | 2 = selective recompute",
+                       "grad_cp1_reference_recipe_same_run": cp_ref, "grad_cp2_selective_same_run": cp_sel},
+            "per_rank": {"tokens_per_step": a.micro_bsz * a.ctx_len, "micro_bsz": a.micro_bsz, "ranks": world,
+                         "data_path_collectives": "none (batch shards); gradients: bucketed reduce-scatter on a side stream during the backward, "
+                                                  "one scalar all-reduce (clip norm), parameter all-gather on the side stream after AdamW"},
+            "comm": comm,
         }
         # roofline of the dominant hot-path kernel (WKV7 backward), HIP events on the launch stream
         kinds = {}
@@ -420,13 +432,19 @@ def main():
             ms = sum(x for x, _ in kinds["bwd"]) / len(kinds["bwd"])
             elems = kinds["bwd"][0][1]
             ach = elems * BWD_B / ms / 1e6
-            out["roofline"] = {"bound": "hbm", "kernel": _wkv7_kernel_name(1), "achieved": ach, "peak": HBM_PEAK_GBPS,
+            shp = (a.micro_bsz, a.ctx_len + (-a.ctx_len) % 16, args.n_embd // 64)
+            out["roofline"] = {"bound": "hbm", "kernel": _wkv7_kernel_name(1, *shp), "achieved": ach, "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
                                "avg_ms": ms, "launches": len(kinds["bwd"]), "algorithmic_bytes": elems * BWD_B}
             if "fwd" in kinds:
                 msf = sum(x for x, _ in kinds["fwd"]) / len(kinds["fwd"])
-                out["roofline"]["fwd_kernel"] = {"kernel": _wkv7_kernel_name(0), "avg_ms": msf,
+                out["roofline"]["fwd_kernel"] = {"kernel": _wkv7_kernel_name(0, *shp), "avg_ms": msf, "launches": len(kinds["fwd"]),
                                                  "achieved": elems * FWD_B / msf / 1e6, "frac": elems * FWD_B / msf / 1e6 / HBM_PEAK_GBPS}
+            if "fwd_state" in kinds:                  # --grad-cp 2: the training forward is the by-product-free entry (2 + 12 B / element)
+                msf = sum(x for x, _ in kinds["fwd_state"]) / len(kinds["fwd_state"])
+                out["roofline"]["fwd_state_kernel"] = {"kernel": _wkv7_kernel_name(2, *shp), "avg_ms": msf, "launches": len(kinds["fwd_state"]),
+                                                       "algorithmic_bytes_per_element": 14, "achieved": elems * 14 / msf / 1e6,
+                                                       "frac": elems * 14 / msf / 1e6 / HBM_PEAK_GBPS}
             copy = stream_copy_gbps(dev)                  # what a plain copy reaches on this box, random bytes
             out["roofline"]["stream_copy_GBps"] = copy
             out["roofline"]["stream_copy_zero_data_GBps"] = stream_copy_gbps(dev, fill="zeros")     # same kernel, higher clock

@@ -28,6 +28,8 @@ def run(B=8, T=2624, H=32, bwd_variant=-1, fwd_variant=-1):
         dbg = torch.zeros(32, dtype=torch.int64, device=dev)
         rc = lib.vrwkv_wkv7_profile_bf16(bw, B, T, H, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), z.data_ptr(), a.data_ptr(),
                                          dy.data_ptr(), y.data_ptr(), s.data_ptr(), sa.data_ptr(), *[x.data_ptr() for x in g], dbg.data_ptr(), st)
+        if rc == -1:                 # VRWKV_EINVAL: this generation is not in the library that is loaded (bw = 3, wkv7_bwd_v7.h, lives in experiment builds only)
+            continue
         assert rc == 0, rc
         torch.cuda.synchronize()
         d = dbg.cpu().tolist()

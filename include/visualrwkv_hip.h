@@ -200,9 +200,15 @@ int vrwkv_wkv7_step_bf16(int B, int H, const void* w, const void* q, const void*
 int vrwkv_wkv7_set_forward_variant(int variant);
 int vrwkv_wkv7_set_backward_variant(int variant);
 /* The kernel generation the LAST vrwkv_wkv7_forward_bf16 (backward == 0) / vrwkv_wkv7_backward_bf16 (backward != 0) launch of this
- * process resolved to, in the numbering above (forward: 7 = wkv7_fwd_v4.h, 6 = two workgroups per head, 4 = wkv7_fwd_v3.h; 0 = none yet):
- * lets a parity test assert WHICH kernel the default dispatch chose for its shape. */
+ * process resolved to, in the numbering above (forward: 7 = wkv7_fwd_v4.h, 6 = two workgroups per head, 4 = wkv7_fwd_v3.h; 0 = none yet);
+ * vrwkv_wkv7_forward_state_bf16 records into the forward slot as well.  Lets a single-threaded parity test assert WHICH kernel the default
+ * dispatch chose for its shape. */
 int vrwkv_wkv7_last_variant(int backward);
+/* Which kernel generation a launch of shape (B,T,H) resolves to under the current override, WITHOUT launching: kind 0 = vrwkv_wkv7_forward_bf16,
+ * 1 = vrwkv_wkv7_backward_bf16, 2 = vrwkv_wkv7_forward_state_bf16 (same rule as kind 0; its A/B overrides 1..5 all mean 4).  A pure function of
+ * its arguments and the override: unlike vrwkv_wkv7_last_variant it does not depend on which thread launched last (the reference calls the op
+ * from the Python thread and from autograd's backward thread).  A bad shape or kind gives VRWKV_EINVAL (< 0). */
+int vrwkv_wkv7_resolve_variant(int kind, int B, int T, int H);
 
 /* ---- Fused element-wise glue of RWKV_Tmix_x070 / RWKV_CMix_x070 (VisualRWKV-v7/v7.00/src/model.py), forward and
  * backward.  Activations are (ntok, C) bf16 contiguous (ntok = B*T), parameters C bf16.  Parameter gradients

@@ -49,7 +49,7 @@ def test_modules_match_reference(gold, fused):
     assert rel_rms(b1.float().cpu(), g["block1_y"].float()) < TOL
 
 
-@pytest.mark.parametrize("fused,grad_cp", [(False, 0), (False, 1), (True, 0), (True, 1), (True, 2)])      # fused: 1 = selective recompute, 2 = every block re-computed
+@pytest.mark.parametrize("fused,grad_cp", [(False, 0), (False, 1), (True, 0), (True, 1), (True, 2)])      # 1 = every block re-computed (the reference's --grad_cp 1), 2 = selective recompute (fused path; eager: same as 1)
 def test_lm_forward_backward_with_padding(gold, fused, grad_cp):
     """RWKV.forward on T=37 (left-padded to 48 with emb(261), model.py:286-312) + backward."""
     m = _lm(gold, fused, grad_cp)
@@ -66,12 +66,12 @@ def test_lm_forward_backward_with_padding(gold, fused, grad_cp):
 
 
 def test_selective_recompute_keeps_less_and_computes_the_same(gold):
-    """grad_cp=1 of the fused path (fused.blocks_forward): the WKV7 chunk checkpoints / sa and relu(h)^2 are not kept for the backward
+    """grad_cp=2 of the fused path (fused.blocks_forward): the WKV7 chunk checkpoints / sa and relu(h)^2 are not kept for the backward
     -- less memory held between forward and backward -- and the gradients are those of grad_cp=0 (the recompute runs the same kernels;
     only y comes from the by-product-free forward entry, another instantiation of the same algorithm)."""
     g = gold["lm"]
     res = {}
-    for mode in (0, 1):
+    for mode in (0, 2):
         m = _lm(gold, True, mode)
         x = torch.cat([g["x"]] * 3, dim=1).cuda().requires_grad_(True)          # T = 111 -> 112: seven chunks
         torch.cuda.synchronize()
@@ -81,10 +81,10 @@ def test_selective_recompute_keeps_less_and_computes_the_same(gold):
         gout = torch.cat([g["gout"]] * 3, dim=1).cuda()
         logits.backward(gout)
         res[mode] = (held, logits.detach().float().cpu(), x.grad.float().cpu(), {n: p.grad.float().cpu() for n, p in m.named_parameters() if p.grad is not None})
-    assert res[1][0] < 0.9 * res[0][0], (res[0][0], res[1][0])
-    assert rel_rms(res[1][1], res[0][1]) < 2e-3 and rel_rms(res[1][2], res[0][2]) < 4e-3
+    assert res[2][0] < 0.9 * res[0][0], (res[0][0], res[2][0])
+    assert rel_rms(res[2][1], res[0][1]) < 2e-3 and rel_rms(res[2][2], res[0][2]) < 4e-3
     for n, gr in res[0][3].items():
-        assert rel_rms(res[1][3][n], gr) < 4e-3, n
+        assert rel_rms(res[2][3][n], gr) < 4e-3, n
 
 
 def test_full_visual_step_runs_and_learns():

@@ -51,7 +51,7 @@ def _capi_backward(lib, w, q, k, v, z, a, dy, s, sa):
     return outs
 
 
-@pytest.mark.parametrize("variant", [-1, 1, 2, 7])        # 7: wkv7_fwd_v4.h (full-row memory traffic); default (no Ab / Kb images + tr16 reads), round-2 instantiation, no Ab / Kb only
+@pytest.mark.parametrize("variant", [-1, 1, 2, 4, 7])     # 7: wkv7_fwd_v4.h (full-row memory traffic); -1: the default dispatch (two workgroups per head at these sizes); 4: the default instantiation of wkv7_fwd_v3.h, one workgroup per head (no Ab / Kb images + tr16 reads); 1: round-2 instantiation; 2: no Ab / Kb only
 @pytest.mark.parametrize("B,T,H", [(1, 16, 1), (2, 64, 3), (1, 384, 12), (3, 208, 5)])
 def test_forward_parity(hip_lib, dev, B, T, H, variant):
     w, q, k, v, z, a, _ = make_inputs(B, T, H, seed=B * 1000 + T + H)
@@ -252,6 +252,118 @@ def test_bench_dispatch_against_oracle(hip_lib, dev, B, T, H):
     del s, sa, sr, sar
     for n, o, r in zip(NAMES, outs, ref):
         bf16_close(o, r.float(), f"bench dispatch {n} {B}x{T}x{H}", tol=TOL, max_flip=FLIP_W if n in ("dw", "dz") else FLIP_G)
+
+
+def _capi_forward_state(lib, w, q, k, v, z, a, s0=None, want_final=True, by_products=False):
+    B, T, H, N = w.shape
+    y = torch.empty_like(v)
+    fin = torch.empty(B, H, N, N, dtype=torch.float32, device=w.device) if want_final else None
+    s = torch.empty(B, H, T // 16, N, N, dtype=torch.float32, device=w.device) if by_products else None
+    sa = torch.empty(B, T, H, N, dtype=torch.float32, device=w.device) if by_products else None
+    ptr = lambda t: t.data_ptr() if t is not None else 0
+    rc = lib.vrwkv_wkv7_forward_state_bf16(B, T, H, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), z.data_ptr(), a.data_ptr(),
+                                           y.data_ptr(), ptr(s0), ptr(fin), ptr(s), ptr(sa), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.vrwkv_strerror(rc)
+    return y, fin, s, sa
+
+
+@pytest.mark.parametrize("B,T,H", [(16, 2624, 32), (8, 6400, 32)])
+def test_forward_state_dispatch_against_oracle(hip_lib, dev, B, T, H):
+    """vrwkv_wkv7_forward_state_bf16 at the bench shapes with NO variant forced -- the forward of the selective-recompute mode
+    (fused.blocks_forward grad_cp=2) and of stateful prefill at scale: without by-products (y only), with them (y, s, sa), and continuing
+    from a non-zero state with the final state returned, every head against the C oracle; which kernel ran is asserted
+    (wkv7_fwd_v4.h for B x H > 128, as in vrwkv_wkv7_forward_bf16)."""
+    assert hip_lib.vrwkv_wkv7_set_forward_variant(-1) == 0
+    assert hip_lib.vrwkv_wkv7_resolve_variant(2, B, T, H) == 7 and hip_lib.vrwkv_wkv7_resolve_variant(0, B, T, H) == 7
+    w, q, k, v, z, a, _ = make_inputs(B, T, H, seed=B + T)
+    yr, sr, sar = wkv7_c.forward(w, q, k, v, z, a)
+    d = [x.to(dev) for x in (w, q, k, v, z, a)]
+    y, fin, _, _ = _capi_forward_state(hip_lib, *d, want_final=False)                      # what WindBackstepping(recompute) launches
+    assert hip_lib.vrwkv_wkv7_last_variant(0) == 7
+    bf16_close(y, yr.float(), f"forward_state y {B}x{T}x{H}", tol=TOL, max_flip=FLIP_Y)
+    y, fin, s, sa = _capi_forward_state(hip_lib, *d, by_products=True)
+    torch.cuda.synchronize()
+    bf16_close(y, yr.float(), f"forward_state y (+by-products) {B}x{T}x{H}", tol=TOL, max_flip=FLIP_Y)
+    assert rel_rms(s.cpu(), sr) < 2e-5 and rel_rms(sa.cpu(), sar) < 2e-5
+    # the final state is the last checkpoint transposed (the op's `s` holds S^T, wkv7_cuda.cu:45-49)
+    assert rel_rms(fin.cpu(), sr[:, :, -1].transpose(-1, -2)) < 2e-5
+    del s, sa
+    # second half from the state after the first half == the second half of the whole sequence (T/2 is a whole number of chunks)
+    Th = T // 2
+    assert Th % 16 == 0
+    h1 = [x[:, :Th].contiguous() for x in d]
+    h2 = [x[:, Th:].contiguous() for x in d]
+    _, mid, _, _ = _capi_forward_state(hip_lib, *h1)
+    assert rel_rms(mid.cpu(), sr[:, :, Th // 16 - 1].transpose(-1, -2)) < 2e-5
+    y2, fin2, _, _ = _capi_forward_state(hip_lib, *h2, s0=mid)
+    torch.cuda.synchronize()
+    bf16_close(y2, yr[:, Th:].float(), f"forward_state from state {B}x{T}x{H}", tol=TOL, max_flip=FLIP_Y)
+    assert rel_rms(fin2.cpu(), sr[:, :, -1].transpose(-1, -2)) < 2e-5
+
+
+def test_recompute_state_autograd_surface_at_bench_size(hip_lib, dev):
+    """WindBackstepping with recompute_state at cfg 3's bench shape (16 x 2624 x 32): the forward keeps the six inputs only (by-product-free
+    entry), the backward re-runs the training forward for s / sa and then the backward kernel -- y and all six gradients against the C oracle."""
+    from visualrwkv_amd import wkv7
+    B, T, H = 16, 2624, 32
+    w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=B + T)
+    yr, sr, sar = wkv7_c.forward(w, q, k, v, z, a)
+    ref = wkv7_c.backward(w, q, k, v, z, a, dy, sr, sar)
+    del sr, sar
+    leaves = [x.to(dev).requires_grad_(True) for x in (w, q, k, v, z, a)]
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    y = wkv7.WindBackstepping.apply(*leaves, True)
+    held = torch.cuda.memory_allocated() - base
+    assert held < 1.5 * y.numel() * 2, held            # y only: no 20 B / element of checkpoints behind the graph
+    y.backward(dy.to(dev))
+    torch.cuda.synchronize()
+    bf16_close(y.detach(), yr.float(), "recompute y", tol=TOL, max_flip=FLIP_Y)
+    for n, l, r in zip(NAMES, leaves, ref):
+        bf16_close(l.grad, r.float(), f"recompute {n}", tol=TOL, max_flip=FLIP_W if n in ("dw", "dz") else FLIP_G)
+    # the reference's six-argument call still works and keeps the by-products
+    leaves2 = [x.detach().clone().requires_grad_(True) for x in leaves]
+    wkv7.WindBackstepping.apply(*leaves2).backward(dy.to(dev))
+    for n, l, l2 in zip(NAMES, leaves, leaves2):
+        assert torch.equal(l.grad, l2.grad), n         # same kernels on the same inputs: bit-identical
+
+
+def test_launches_from_two_threads(hip_lib, dev):
+    """The op is called from the Python thread and from autograd's backward thread: two threads launching different shapes
+    on their own streams at once both get right results, and vrwkv_wkv7_resolve_variant (a pure function) names each launch's kernel
+    whatever the other thread did last."""
+    import threading
+    shapes = [(2, 64, 3), (5, 208, 64)]                # B x H = 6 (two workgroups per head) | 320 (v4, backward variant 9)
+    refs, outs, errs = {}, {}, []
+    for sh in shapes:
+        w, q, k, v, z, a, dy = make_inputs(*sh, seed=sum(sh))
+        yr, sr, sar = wkv7_c.forward(w, q, k, v, z, a)
+        refs[sh] = ((w, q, k, v, z, a, dy), yr, wkv7_c.backward(w, q, k, v, z, a, dy, sr, sar))
+
+    def work(sh):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                d = [x.to(dev) for x in refs[sh][0]]
+                for _ in range(20):
+                    y, s, sa = _capi_forward(hip_lib, *d[:6])
+                    g = _capi_backward(hip_lib, *d, s, sa)
+                st.synchronize()
+                outs[sh] = (y, g)
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(sh,)) for sh in shapes]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    assert hip_lib.vrwkv_wkv7_resolve_variant(0, *shapes[0]) == 6 and hip_lib.vrwkv_wkv7_resolve_variant(1, *shapes[0]) == 8
+    assert hip_lib.vrwkv_wkv7_resolve_variant(0, *shapes[1]) == 7 and hip_lib.vrwkv_wkv7_resolve_variant(1, *shapes[1]) == 9
+    for sh in shapes:
+        _, yr, gr = refs[sh]
+        assert rel_rms(outs[sh][0].float().cpu(), yr.float()) < TOL
+        for n, o, r in zip(NAMES, outs[sh][1], gr):
+            assert rel_rms(o.float().cpu(), r.float()) < TOL, (sh, n)
 
 
 @pytest.mark.parametrize("tpar", [False, True])

@@ -130,11 +130,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True)
             os.replace(tmp, LIB_PATH)
-            with open(HASH_PATH, "w") as f:
-                f.write(_digest())
+            _write_atomic(HASH_PATH, _digest())
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
+
+
+def _write_atomic(path: str, text: str) -> None:
+    """A reader never sees the file empty or half written (a concurrent rank would take that for "stale" and rebuild)."""
+    tmp = f"{path}.tmp{os.getpid()}"
+    with open(tmp, "w") as f:
+        f.write(text)
+    os.replace(tmp, path)
 
 
 def build_host(force: bool = False) -> str:
@@ -149,25 +156,30 @@ def build_host(force: bool = False) -> str:
         with open(d, "rb") as f:
             h.update(f.read())
     digest, hash_path = h.hexdigest(), HOST_LIB_PATH + ".hash"       # content hash, as for the HIP library: mtimes do not survive a copy
-    if not force and os.path.exists(HOST_LIB_PATH):
+
+    def fresh():
+        if force or not os.path.exists(HOST_LIB_PATH):
+            return False
         try:
             with open(hash_path) as f:
-                if f.read().strip() == digest:
-                    return HOST_LIB_PATH
+                return f.read().strip() == digest
         except OSError:
-            pass
+            return False
+    if fresh():
+        return HOST_LIB_PATH
     cxx = shutil.which("g++") or shutil.which("clang++") or shutil.which("c++")
     if cxx is None:
         raise RuntimeError("no host C++ compiler (g++ / clang++) found for libvisualrwkv_host.so")
     with open(HOST_LIB_PATH + ".lock", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
+            if fresh():                                   # another rank built it while this one waited for the lock
+                return HOST_LIB_PATH
             tmp = f"{HOST_LIB_PATH}.tmp{os.getpid()}"
             subprocess.run([cxx, "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-x", "c++", "-I", os.path.join(REPO_DIR, "include"),
                             src, "-o", tmp], check=True)
             os.replace(tmp, HOST_LIB_PATH)
-            with open(hash_path, "w") as f:
-                f.write(digest)
+            _write_atomic(hash_path, digest)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return HOST_LIB_PATH

@@ -1,6 +1,7 @@
 // Host launchers + C-ABI for the WKV7 kernels (include/visualrwkv_hip.h).  The profiling entry point is wkv7_profile.hip; A/B partners
 // that are not part of the product (wkv7_bwd_v7.h, builds with one or two wave roles switched off, the tail on the J waves) come in
 // through benchmarks/experiments/wkv7_experiments.h when the library is built with -DVRWKV_V6_EXPERIMENTS (benchmarks/build_alt.sh).
+#include <atomic>
 #include <wkv7_launch.h>
 #include <wkv7_chunked.h>
 #include <wkv7_fwd_v3.h>
@@ -13,12 +14,15 @@
 #endif
 
 namespace wkv7launch {
-int g_fwd_variant = -1, g_bwd_variant = -1;
+std::atomic<int> g_fwd_variant{-1}, g_bwd_variant{-1};
 }
 
 namespace {
 using namespace wkv7launch;
-int g_last_fwd = 0, g_last_bwd = 0;     // what the last launch of each direction resolved to (vrwkv_wkv7_last_variant)
+// what the last launch of each direction resolved to (vrwkv_wkv7_last_variant): a single-threaded test aid -- launches come from the
+// Python thread AND from autograd's backward thread, so code that needs to know which kernel a launch of a given shape uses asks
+// vrwkv_wkv7_resolve_variant (a pure function of the shape and the override) instead of reading this after the fact
+std::atomic<int> g_last_fwd{0}, g_last_bwd{0};
 // Forward default: no Ab / Kb images (state update from Ah / Kh, scaled by c_L afterwards; T chain splitting every matrix once
 // per level) + natural [t][j] images read with ds_read_b64_tr_b16.  Same-box A/B (benchmarks/wkv7_ab.py --fwd 1 2 4): B=8
 // 0.358 -> 0.331 -> 0.324 ms, B=16 0.647 -> 0.637 -> 0.627 ms.  Variant 1 = the round-2 instantiation.
@@ -27,6 +31,19 @@ int g_last_fwd = 0, g_last_bwd = 0;     // what the last launch of each directio
 // backward: 5 = wkv7_bwd_v5.h (8 waves; also the sequence-parallel kernel), 6 = wkv7_bwd_v6.h (12-wave pipeline, 8-byte register loads: tensors of
 // 4 GiB and more), 8 = wkv7_bwd_v8.h (one dS copy, T chain on P wave 0, full-row LDS-DMA), 9 = 8 with the score pieces a step ahead on the P waves
 constexpr int BWD_DEFAULT = 9;
+
+// The kernel a forward launch of `heads` = B x H workgroups uses under override `forced` (-1: none): 7 = wkv7_fwd_v4.h (full-row memory traffic)
+// when the heads alone give every CU a workgroup pair's worth of work, 6 = wkv7_fwd_v3.h with two workgroups per head below that, else the forced
+// instantiation of wkv7_fwd_v3.h.  The stateful entry (vrwkv_wkv7_forward_state_bf16) follows the same rule; its A/B overrides 1..5 all mean 4
+// (the default instantiation of wkv7_fwd_v3.h: the others have no state arguments).
+int resolve_fwd(long heads, int forced, bool stateful) {
+    if (forced == 7 || (forced == -1 && heads > FWD_ISPLIT_MAX_HEADS)) return 7;
+    if (forced == -1) return 6;
+    return stateful ? 4 : forced;
+}
+// backward: variant 9 when the launch has more workgroups than the chip has CUs (measured -0.4 ... -2.3 % at B x H = 384 ... 1024), variant 8
+// for a single round of workgroups (B x H <= 256: 9 measured +0.3 ... +1.8 % there); profiles/r4_wkv7_ab.jsonl, r4c_wkv7_ab.jsonl
+int resolve_bwd(long heads, int forced) { return forced == -1 ? (heads > 256 ? BWD_DEFAULT : 8) : forced; }
 }  // namespace
 
 extern "C" {
@@ -59,7 +76,14 @@ int vrwkv_wkv7_set_backward_variant(int variant) {
     return VRWKV_OK;
 }
 
-int vrwkv_wkv7_last_variant(int backward) { return backward ? g_last_bwd : g_last_fwd; }
+int vrwkv_wkv7_last_variant(int backward) { return backward ? g_last_bwd.load() : g_last_fwd.load(); }
+
+int vrwkv_wkv7_resolve_variant(int kind, int B, int T, int H) {
+    if (check_common(B, T, H) != VRWKV_OK || kind < 0 || kind > 2) return VRWKV_EINVAL;
+    const long heads = (long)B * H;
+    if (kind == 1) return resolve_bwd(heads, g_bwd_variant.load());
+    return resolve_fwd(heads, g_fwd_variant.load(), kind == 2);
+}
 
 int vrwkv_wkv7_forward_bf16(int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
                             const void* z, const void* a, void* y, float* s, float* sa, void* stream) {
@@ -74,20 +98,18 @@ int vrwkv_wkv7_forward_bf16(int B, int T, int H, const void* w, const void* q, c
     hipStream_t st = (hipStream_t)stream;
     const long heads = (long)B * H;
     const dim3 grid((unsigned)heads);
-    if (g_fwd_variant == 7 || (g_fwd_variant == -1 && heads > FWD_ISPLIT_MAX_HEADS)) {      // full-row memory traffic (wkv7_fwd_v4.h)
-        g_last_fwd = 7;
+    const int var = resolve_fwd(heads, g_fwd_variant.load(), false);
+    g_last_fwd = var;
+    if (var == 7)        // full-row memory traffic (wkv7_fwd_v4.h)
         return launch_lds(&wkv7f4::fwd_kernel_v4<false>, grid, dim3(512), sizeof(wkv7f4::LdsF4), st, p);
-    }
-    // chunked MFMA, producer / consumer waves (wkv7_fwd_v3.h)
+    // chunked MFMA, producer / consumer waves (wkv7_fwd_v3.h); 6: two workgroups per head; 4: its default instantiation
     void (*kern)(wkv7::FwdArgs) = &VRWKV_FWD_DEFAULT;
-    if (g_fwd_variant == 1) kern = &wkv7c::fwd_kernel_v3<false, false, 1>;
-    if (g_fwd_variant == 2) kern = &wkv7c::fwd_kernel_v3<false, false, 1, 1, false, false, true>;
-    if (g_fwd_variant == 3) kern = &wkv7c::fwd_kernel_v3<false, true, 1, 1, false, false, true>;     // + 16-byte transposed stores
-    if (g_fwd_variant == 5) kern = &wkv7c::fwd_kernel_v3<false, false, 1, 2, false, false, true>;     // + two chunks of prefetch
-    const bool split = g_fwd_variant == -1;                                                           // here: heads <= FWD_ISPLIT_MAX_HEADS
-    if (split) kern = &VRWKV_FWD_ISPLIT;
-    g_last_fwd = split ? 6 : g_fwd_variant;      // 6: two workgroups per head; 4: the default instantiation of wkv7_fwd_v3.h
-    return launch_lds(kern, split ? dim3((unsigned)(2 * heads)) : grid, dim3(512), sizeof(wkv7c::LdsF), st, p);
+    if (var == 1) kern = &wkv7c::fwd_kernel_v3<false, false, 1>;
+    if (var == 2) kern = &wkv7c::fwd_kernel_v3<false, false, 1, 1, false, false, true>;
+    if (var == 3) kern = &wkv7c::fwd_kernel_v3<false, true, 1, 1, false, false, true>;     // + 16-byte transposed stores
+    if (var == 5) kern = &wkv7c::fwd_kernel_v3<false, false, 1, 2, false, false, true>;     // + two chunks of prefetch
+    if (var == 6) kern = &VRWKV_FWD_ISPLIT;
+    return launch_lds(kern, var == 6 ? dim3((unsigned)(2 * heads)) : grid, dim3(512), sizeof(wkv7c::LdsF), st, p);
 }
 
 int vrwkv_wkv7_forward_state_bf16(int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
@@ -101,10 +123,14 @@ int vrwkv_wkv7_forward_state_bf16(int B, int T, int H, const void* w, const void
         return VRWKV_EALIGN;
     const wkv7::FwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
                           (const uint16_t*)z, (const uint16_t*)a, (uint16_t*)y, s_ckpt, sa, nullptr, s0, s_final};
+    // same dispatch as the training forward: the full-row kernel when the heads fill the chip (it takes the state arguments and skips the
+    // by-products it has no buffers for), two workgroups per head below that
     const long heads = (long)B * H;
-    const bool split = g_fwd_variant == -1 && heads <= FWD_ISPLIT_MAX_HEADS;
-    void (*kern)(wkv7::FwdArgs) = split ? &VRWKV_FWD_ISPLIT : &VRWKV_FWD_DEFAULT;
-    return launch_lds(kern, dim3((unsigned)(split ? 2 * heads : heads)), dim3(512), sizeof(wkv7c::LdsF), (hipStream_t)stream, p);
+    const int var = resolve_fwd(heads, g_fwd_variant.load(), true);
+    g_last_fwd = var;
+    if (var == 7) return launch_lds(&wkv7f4::fwd_kernel_v4<false>, dim3((unsigned)heads), dim3(512), sizeof(wkv7f4::LdsF4), (hipStream_t)stream, p);
+    void (*kern)(wkv7::FwdArgs) = var == 6 ? &VRWKV_FWD_ISPLIT : &VRWKV_FWD_DEFAULT;
+    return launch_lds(kern, dim3((unsigned)(var == 6 ? 2 * heads : heads)), dim3(512), sizeof(wkv7c::LdsF), (hipStream_t)stream, p);
 }
 
 int vrwkv_wkv7_backward_bf16(int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
@@ -122,9 +148,7 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H, const void* w, const void* q, 
                           (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)((long)B * H));
-    // default: variant 9 when the launch has more workgroups than the chip has CUs (measured -0.4 ... -2.3 % at B x H = 384 ... 1024), variant 8
-    // for a single round of workgroups (B x H <= 256: 9 measured +0.3 ... +1.8 % there); profiles/r4_wkv7_ab.jsonl, r4c_wkv7_ab.jsonl
-    int var = g_bwd_variant == -1 ? ((long)B * H > 256 ? BWD_DEFAULT : 8) : g_bwd_variant;
+    int var = resolve_bwd((long)B * H, g_bwd_variant.load());
     const bool fits32 = (unsigned long long)B * T * H * 64ull * 4ull < (1ull << 32);      // wkv7_bwd_v8.h uses 32-bit byte offsets inside a tensor
     if (!fits32 && var >= 8) var = 6;
     g_last_bwd = var;

@@ -2,13 +2,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #include "../../include/visualrwkv_hip.h"
 #include <wkv7_kernels.h>
 
 namespace wkv7launch {
 
-extern int g_fwd_variant, g_bwd_variant;      // vrwkv_wkv7_set_{forward,backward}_variant; -1 = default
+extern std::atomic<int> g_fwd_variant, g_bwd_variant;      // vrwkv_wkv7_set_{forward,backward}_variant; -1 = default
 // few heads (B*H <= 128: at most half of the 256 CUs would be busy): the forward runs two workgroups per head, 32 value rows each
 constexpr long FWD_ISPLIT_MAX_HEADS = 128;
 // T chain on the bf16 matrix core (2) + producer priority 2 (4; same-box A/B: 1.18 -> 1.09 ms) + priorities swapped in

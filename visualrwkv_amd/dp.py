@@ -157,6 +157,10 @@ class Zero1Engine:
         self._next_launch = 0
         self._gather_event = None
         self.generation = 0
+        # comm_timing (bench.py, N > 1): when a list, every collective is bracketed by timing events on the communication stream and every
+        # point where the COMPUTE stream waits for communication by timing events on the compute stream; comm_report() turns them into
+        # "how long did the collectives run" and "how much of that did the compute stream stand still for" (the exposed part)
+        self.comm_timing = None
         self._wait_hooks = []
         if self.async_gather:
             # the parameter all-gather runs on the side stream; whoever first touches a trainable parameter in the next
@@ -236,11 +240,42 @@ class Zero1Engine:
             ready.record(torch.cuda.current_stream(self.device))
             self.comm_stream.wait_event(ready)
             with torch.cuda.stream(self.comm_stream):
+                t0 = self._mark(self.comm_stream)
                 self._reduce_scatter(buf, b)
+                self._mark_end("reduce_scatter", t0, self.comm_stream)
                 b.event = torch.cuda.Event()
                 b.event.record(self.comm_stream)
         else:
             self._reduce_scatter(buf, b)
+
+    def _mark(self, stream):
+        if self.comm_timing is None or not self.on_gpu:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(stream)
+        return e
+
+    def _mark_end(self, kind, t0, stream):
+        if t0 is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(stream)
+            self.comm_timing.append((kind, t0, e))
+
+    def comm_report(self, steps: int):
+        """Per-step averages (ms) over the events collected since comm_timing was set to a list: time the collectives occupied the
+        communication stream, and time the compute stream stood still waiting for them (after the backward for the last reduce-scatters,
+        before the first trainable module of the next forward for the all-gather).  Synchronises."""
+        if not self.comm_timing:
+            return None
+        torch.cuda.synchronize(self.device)
+        tot = {}
+        for kind, a, b in self.comm_timing:
+            tot[kind] = tot.get(kind, 0.0) + a.elapsed_time(b)
+        out = {k + "_ms_per_step": v / max(steps, 1) for k, v in tot.items()}
+        out["exposed_ms_per_step"] = (tot.get("wait_reduce_scatter", 0.0) + tot.get("wait_all_gather", 0.0)) / max(steps, 1)
+        out["what"] = ("reduce_scatter / all_gather: time on the communication stream (includes waiting for the slowest rank); wait_*: time the "
+                       "compute stream stood still for them = the exposed communication")
+        return out
 
     def _reduce_scatter(self, buf, b: _Bucket):
         piece = buf[self.rank * b.piece:(self.rank + 1) * b.piece]
@@ -298,9 +333,12 @@ class Zero1Engine:
         self._next_launch = len(self.buckets)
         if self.collective:
             if self.overlap:
+                cur = torch.cuda.current_stream(self.device)
+                t0 = self._mark(cur)
                 for b in self.buckets:
                     if b.event is not None:
-                        torch.cuda.current_stream(self.device).wait_event(b.event)
+                        cur.wait_event(b.event)
+                self._mark_end("wait_reduce_scatter", t0, cur)
         inv_world = 1.0 / self.world
         # global gradient norm over the owned pieces (each element is owned by exactly one rank)
         self._sq.zero_()
@@ -326,7 +364,9 @@ class Zero1Engine:
                 done.record(torch.cuda.current_stream(self.device))
                 self.comm_stream.wait_event(done)
                 with torch.cuda.stream(self.comm_stream):
+                    t0 = self._mark(self.comm_stream)
                     self._all_gather()
+                    self._mark_end("all_gather", t0, self.comm_stream)
                     self._gather_event = torch.cuda.Event()
                     self._gather_event.record(self.comm_stream)
                 if not self.async_gather:
@@ -352,7 +392,10 @@ class Zero1Engine:
         """Make the current stream wait for the parameter all-gather of the last step (no-op when none is pending)."""
         ev, self._gather_event = self._gather_event, None
         if ev is not None:
-            torch.cuda.current_stream(self.device).wait_event(ev)
+            cur = torch.cuda.current_stream(self.device)
+            t0 = self._mark(cur)
+            cur.wait_event(ev)
+            self._mark_end("wait_all_gather", t0, cur)
 
     def close(self):
         """Detach the engine from its parameters: weight-gradient GEMMs stop writing into this engine's flat buffer (a model that

@@ -407,7 +407,7 @@ class _ReluSq(torch.autograd.Function):
 class _ReluSqLinear(torch.autograd.Function):
     """value(relu(h)^2) of the channel-mix (src/model.py:225-226) WITHOUT keeping relu(h)^2 for the backward: 4 of the ~40 activation
     tensors a layer keeps (it is as wide as the FFN).  The backward forms it again from h (one streaming kernel, 0.21 ms per layer at
-    micro-batch 16) for the weight gradient.  Selective recompute (`grad_cp=1`) only; gradients are those of relu_sq + _LinearTN."""
+    micro-batch 16) for the weight gradient.  Selective recompute (`grad_cp=2`) only; gradients are those of relu_sq + _LinearTN."""
 
     @staticmethod
     def forward(ctx, h, w):
@@ -600,20 +600,21 @@ def add_ln_supported(x):
     return x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 64 == 0 and x.shape[-1] <= 8192
 
 
-def _block_segment(block, x, delta, v_first):
-    """One Block on the (x, pending delta) residual stream: returns (x + delta, ffn output still to be added, v_first)."""
+def _block_segment(block, x, delta, v_first, selective=False):
+    """One Block on the (x, pending delta) residual stream: returns (x + delta, ffn output still to be added, v_first).
+    selective: the selective-recompute mode of blocks_forward (WKV7 by-products and relu(h)^2 are re-formed in the backward)."""
     att, ffn = block.att, block.ffn
     fuse = ln_mix_supported(x) and getattr(att.args, "fused", False)
     if fuse and LN_MIX_TMIX:
         dup3 = torch.is_grad_enabled() and GRAD_ALIAS and att.layer_id > 0
         x, mixed = add_ln_mix(x, delta, block.ln1, (att.x_r, att.x_w, att.x_k, att.x_v, att.x_a, att.x_g), dup3)
-        att_out, v_first = tmix_from_mixed(att, mixed, v_first)
+        att_out, v_first = tmix_from_mixed(att, mixed, v_first, recompute_state=selective)
     else:
         x, h = add_ln(x, delta, block.ln1)
-        att_out, v_first = att(h, v_first)
+        att_out, v_first = tmix_forward(att, h, v_first, recompute_state=selective) if getattr(att.args, "fused", False) else att(h, v_first)
     if fuse:            # ln2 + the channel-mix lerp in one kernel: the LayerNorm output is never materialised
         x, (k,) = add_ln_mix(x, att_out, block.ln2, (ffn.x_k,))
-        return x, cmix_from_mixed(ffn, k), v_first
+        return x, cmix_from_mixed(ffn, k, recompute_relusq=selective), v_first
     x, h = add_ln(x, att_out, block.ln2)
     return x, ffn(h), v_first
 
@@ -623,29 +624,25 @@ def blocks_forward(rwkv, x, grad_cp=0):
     src/model.py:247-254,313-318): the residual stream is carried as (x, pending delta).
     grad_cp (the reference's memory-saving switch, src/model.py:318-319: deepspeed.checkpointing.checkpoint per block):
       0  keep every activation (288 GB of HBM hold the 1.5B model at micro-batch 16: 192 GB);
-      1  SELECTIVE recompute: keep what is expensive to recompute (every GEMM output), drop what is cheap to recompute and large -- the WKV7
-         chunk checkpoints `s` and `sa` (10 of the ~40 activation tensors of a layer: the backward re-runs the forward kernel) and relu(h)^2 of
-         the channel-mix (4 of them: one streaming kernel) -- about a third of the activation memory for ~1 ms per layer;
-      2  the reference's recipe: every Block re-computed in the backward -- through these same fused kernels, so the recompute and the
-         backward use add_ln / the glue kernels / the WKV7 op, not the eager modules."""
-    global SELECTIVE_RECOMPUTE
-    from . import wkv7
-    grad_cp = int(grad_cp)
+      1  THE REFERENCE'S RECIPE, same memory behaviour: every Block re-computed in the backward (block inputs only are kept: 42 GB) -- through
+         these same fused kernels, so the recompute and the backward use add_ln / the glue kernels / the WKV7 op, not the eager modules;
+      2  (not in the reference) SELECTIVE recompute: keep what is expensive to recompute (every GEMM output), drop what is cheap to recompute and
+         large -- the WKV7 chunk checkpoints `s` and `sa` (10 of the ~40 activation tensors of a layer: the backward re-runs the forward kernel)
+         and relu(h)^2 of the channel-mix (4 of them: one streaming kernel) -- about a third of the activation memory for ~1 ms per layer.
+    (Rounds 4-5 had 1 and 2 the other way round; a trainer configured for the reference's `--grad_cp 1` must not get the mode that needs 3x
+    the memory.)"""
+    grad_cp = int(grad_cp) if torch.is_grad_enabled() else 0
+    if grad_cp not in (0, 1, 2):
+        raise ValueError(f"grad_cp = {grad_cp}: 0 (keep everything), 1 (re-compute every block, the reference's recipe) or 2 (selective recompute)")
     x = rwkv.blocks[0].ln0(x)
     v_first = torch.empty_like(x)
     delta = None
-    prev = SELECTIVE_RECOMPUTE
-    SELECTIVE_RECOMPUTE = grad_cp == 1 and torch.is_grad_enabled()
-    try:
-        with wkv7.recompute_state(SELECTIVE_RECOMPUTE):
-            for block in rwkv.blocks:
-                if grad_cp >= 2:
-                    from torch.utils.checkpoint import checkpoint
-                    x, delta, v_first = checkpoint(_block_segment, block, x, delta, v_first, use_reentrant=False)
-                else:
-                    x, delta, v_first = _block_segment(block, x, delta, v_first)
-    finally:
-        SELECTIVE_RECOMPUTE = prev
+    for block in rwkv.blocks:
+        if grad_cp == 1:
+            from torch.utils.checkpoint import checkpoint
+            x, delta, v_first = checkpoint(_block_segment, block, x, delta, v_first, use_reentrant=False)
+        else:
+            x, delta, v_first = _block_segment(block, x, delta, v_first, grad_cp == 2)
     _, h = add_ln(x, delta, rwkv.ln_out)
     return h
 
@@ -831,17 +828,17 @@ def blocks6_forward(rwkv, x, wkv=None, grad_cp=False):
     return h
 
 
-def tmix_forward(m, x, v_first):
+def tmix_forward(m, x, v_first, recompute_state=False):
     """RWKV_Tmix_x070.forward (src/model.py:163-195) with the glue fused; `m` is the module."""
     train = torch.is_grad_enabled()
     if train and GRAD_ALIAS and m.layer_id > 0:          # x_v, k2, v2 have two consumers each: aliases keep their gradients apart until the
         mixed = mix_dup3(x, m.x_r, m.x_w, m.x_k, m.x_v, m.x_a, m.x_g)      # backward kernels sum them
     else:
         mixed = mix(x, m.x_r, m.x_w, m.x_k, m.x_v, m.x_a, m.x_g)
-    return tmix_from_mixed(m, mixed, v_first)
+    return tmix_from_mixed(m, mixed, v_first, recompute_state)
 
 
-def tmix_from_mixed(m, mixed, v_first):
+def tmix_from_mixed(m, mixed, v_first, recompute_state=False):
     """The time-mix after its token shift: `mixed` = (xr, xw, xk, xv, xa, xg[, alias of xv for its second consumer])."""
     xr, xw, xk, xv, xa, xg = mixed[:6]
     xv_b = mixed[6] if len(mixed) > 6 else xv
@@ -865,7 +862,7 @@ def tmix_from_mixed(m, mixed, v_first):
             k2, v2, z, b, k2_b, v2_b = kva(k, v, v_first, vl, al, m.k_k, m.k_a, m.a0, m.v0, True)
         if not GRAD_ALIAS:
             k2_b, v2_b = k2, v2
-    y = RUN_CUDA_RWKV7g(r, w, k2, v2, z, b)
+    y = RUN_CUDA_RWKV7g(r, w, k2, v2, z, b, recompute_state=recompute_state)
     y = post(y, r, k2_b, v2_b, g, m.ln_x.weight, m.ln_x.bias, m.r_k, m.ln_x.eps)
     return linear(m.output, y), v_first
 
@@ -922,12 +919,9 @@ def cmix_forward(m, x):
     return cmix_from_mixed(m, k)
 
 
-SELECTIVE_RECOMPUTE = False        # set by blocks_forward(grad_cp=1) around the block stack: see _ReluSqLinear, wkv7.RECOMPUTE_STATE
-
-
-def cmix_from_mixed(m, k):
+def cmix_from_mixed(m, k, recompute_relusq=False):
     h = linear(m.key, k)
-    if (SELECTIVE_RECOMPUTE and DGRAD_TN and m.value.bias is None and h.is_cuda and h.dtype == torch.bfloat16 and torch.is_grad_enabled()
+    if (recompute_relusq and DGRAD_TN and m.value.bias is None and h.is_cuda and h.dtype == torch.bfloat16 and torch.is_grad_enabled()
             and h.requires_grad):
         return _ReluSqLinear.apply(h, m.value.weight)
     return linear(m.value, relu_sq(h))

@@ -45,6 +45,7 @@ PROTOTYPES = {
     "vrwkv_wkv7_set_forward_variant": (_c_int, [_c_int]),
     "vrwkv_wkv7_set_backward_variant": (_c_int, [_c_int]),
     "vrwkv_wkv7_last_variant": (_c_int, [_c_int]),
+    "vrwkv_wkv7_resolve_variant": (_c_int, [_c_int] * 4),
     "vrwkv_mix_fwd_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int, _c_int] + [_c_void_p] * 4),
     "vrwkv_mix_fwd_prev_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int, _c_int] + [_c_void_p] * 5),
     "vrwkv_param_grad_ws_floats": (ctypes.c_long, [ctypes.c_long, _c_int, _c_int]),
@@ -133,8 +134,11 @@ def load_host() -> ctypes.CDLL:
         try:
             from .build import build_host
             path = build_host()                              # no-op when the library is newer than its source; rebuilds a stale one
-        except Exception:
+        except Exception as e:      # noqa: BLE001
             if os.path.exists(HOST_LIB_PATH):                # no host compiler here (e.g. a deployment box): use what travelled with the tree
+                import warnings
+                warnings.warn(f"libvisualrwkv_host.so could not be rebuilt ({type(e).__name__}: {e}); using the existing library, which may "
+                              "not match csrc/wkv7_host.hip", RuntimeWarning)
                 path = HOST_LIB_PATH
             else:                                            # the HIP library carries the same code
                 _host_lib = load()

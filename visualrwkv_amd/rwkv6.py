@@ -173,10 +173,10 @@ class RWKV(nn.Module):
         if getattr(args, "fused", False) and args.dropout == 0:
             from . import fused
             if fused.supported6(x) and fused.add_ln_supported(x) and self.head.weight.dtype == torch.bfloat16:
-                h = fused.blocks6_forward(self, x, wkv, grad_cp=args.grad_cp == 1 and torch.is_grad_enabled())
+                h = fused.blocks6_forward(self, x, wkv, grad_cp=args.grad_cp >= 1 and torch.is_grad_enabled())
                 return fused.linear(self.head, h)
         for block in self.blocks:
-            if args.grad_cp == 1 and torch.is_grad_enabled():
+            if args.grad_cp >= 1 and torch.is_grad_enabled():      # 2 (the v7 fused path's selective mode) means 1 here
                 from torch.utils.checkpoint import checkpoint
                 x = checkpoint(block, x, wkv, use_reentrant=False)
             else:

@@ -267,9 +267,9 @@ class RWKV(nn.Module):
 
     `forward(x_emb)` left-pads T to a multiple of CHUNK_LEN with emb(STOP_TOKEN_INDEX) and strips the
     pad from the logits.  `args.grad_cp` is the reference's memory-saving switch (src/model.py:318-319: deepspeed.checkpointing.checkpoint per
-    Block).  Eager path: >= 1 re-computes each Block in the backward (torch.utils.checkpoint -- same schedule).  Fused path
-    (fused.blocks_forward): 1 = selective recompute (WKV7 checkpoints + relu^2 dropped, every GEMM output kept: a third of the activation memory for
-    ~4 % of the step), 2 = every Block re-computed as the reference does."""
+    Block).  1 re-computes each Block in the backward, as the reference does (eager path: torch.utils.checkpoint, fused path: the same schedule
+    through the fused kernels); 2 (not in the reference; fused path) = selective recompute -- WKV7 checkpoints + relu^2 dropped, every GEMM output
+    kept: a third of the activation memory saved for ~4 % of the step; on the eager path 2 falls back to 1."""
 
     def __init__(self, args):
         super().__init__()

@@ -54,7 +54,7 @@ class VisualRWKV6(nn.Module):
             rev = i % 2 == 1
             if rev:                                                    # odd layers read the image span right to left
                 x = torch.cat((x[:, :s], x[:, s:e].flip(1), x[:, e:]), dim=1)
-            if args.grad_cp == 1 and torch.is_grad_enabled():
+            if args.grad_cp >= 1 and torch.is_grad_enabled():      # 2 (the v7 fused path's selective mode) means 1 here
                 from torch.utils.checkpoint import checkpoint
                 x = checkpoint(block, x, wkv, use_reentrant=False)
             else:

@@ -193,40 +193,27 @@ _LIB = _register()
 _apply_variant_env()
 
 
-# Selective activation recompute (`--grad_cp 1` of the fused path, fused.blocks_forward): while this is True a training forward keeps
-# neither the chunk checkpoints `s` (16 B / element) nor `sa` (4 B / element) -- 10 of the ~40 activation tensors a 1.5B layer keeps --
-# and the backward re-runs the forward kernel to get them back (0.59 ms per layer at micro-batch 16).  The forward itself then runs
-# the entry without by-products (2 instead of 24 output bytes per element).
-RECOMPUTE_STATE = False
-
-
-class recompute_state:
-    """with wkv7.recompute_state(True): ... -- scoped switch of RECOMPUTE_STATE."""
-
-    def __init__(self, on=True):
-        self.on = bool(on)
-
-    def __enter__(self):
-        global RECOMPUTE_STATE
-        self.prev, RECOMPUTE_STATE = RECOMPUTE_STATE, self.on
-
-    def __exit__(self, *exc):
-        global RECOMPUTE_STATE
-        RECOMPUTE_STATE = self.prev
+# Selective activation recompute (fused.blocks_forward's memory mode 2): a training forward called with recompute_state=True keeps neither
+# the chunk checkpoints `s` (16 B / element) nor `sa` (4 B / element) -- 10 of the ~40 activation tensors a 1.5B layer keeps -- and the
+# backward re-runs the forward kernel to get them back (0.57 ms per layer at micro-batch 16).  The forward itself then runs the entry
+# without by-products (2 instead of 24 output bytes per element).  The switch is an ARGUMENT of the call (WindBackstepping.apply(..., True),
+# RUN_CUDA_RWKV7g(..., recompute_state=True)), not module state: forward and backward run on different threads.
 
 
 class WindBackstepping(torch.autograd.Function):
     """src/model.py:45-65 (same asserts, same saved tensors, same allocation pattern)."""
 
     @staticmethod
-    def forward(ctx, w, q, k, v, z, b):
+    def forward(ctx, w, q, k, v, z, b, *extra):
+        # extra: () as the reference calls it, or (recompute_state,) -- see the note above
+        ctx.n_extra = len(extra)
         B, T, H, C = w.shape
         assert T % CHUNK_LEN == 0
         # bf16 as in the reference; float32 only for the CPU key (BASELINE config 1, RWKV_FLOAT_MODE=fp32)
         assert all(i.dtype == torch.bfloat16 or (i.dtype == torch.float32 and not i.is_cuda) for i in [w, q, k, v, z, b])
         assert all(i.is_contiguous() for i in [w, q, k, v, z, b])
         P = tparallel_segments(B, H, T, forward=True) if TPARALLEL_BWD and w.is_cuda else 1
-        ctx.recompute = bool(RECOMPUTE_STATE and w.is_cuda and w.dtype == torch.bfloat16 and P == 1)
+        ctx.recompute = bool(extra and extra[0] and w.is_cuda and w.dtype == torch.bfloat16 and P == 1)
         if ctx.recompute:                               # y only; the backward regenerates s and sa
             y, _ = wkv7_forward_state(w, q, k, v, z, b, None, want_state=False)
             ctx.save_for_backward(w, q, k, v, z, b)
@@ -257,16 +244,19 @@ class WindBackstepping(torch.autograd.Function):
             B, T, H, _ = w.shape
             P = tparallel_segments(B, H, T)
             if P > 1:
-                return wkv7_backward_tparallel(w, q, k, v, z, b, dy, s, sa, P)
+                return (*wkv7_backward_tparallel(w, q, k, v, z, b, dy, s, sa, P), *([None] * ctx.n_extra))
         dw, dq, dk, dv, dz, db = [torch.empty_like(x) for x in [w, q, k, v, z, b]]
         torch.ops.wind_backstepping.backward(w, q, k, v, z, b, dy, s, sa, dw, dq, dk, dv, dz, db)
-        return dw, dq, dk, dv, dz, db
+        return (dw, dq, dk, dv, dz, db, *([None] * ctx.n_extra))
 
 
-def RUN_CUDA_RWKV7g(q, w, k, v, a, b):
-    """src/model.py:67-70: (B,T,HC) views -> (B,T,H,64); note the (w,q,...) argument re-order."""
+def RUN_CUDA_RWKV7g(q, w, k, v, a, b, recompute_state=False):
+    """src/model.py:67-70: (B,T,HC) views -> (B,T,H,64); note the (w,q,...) argument re-order.  recompute_state (not in the reference):
+    keep only the six inputs for the backward and re-run the forward kernel there for the by-products `s` and `sa`."""
     B, T, HC = q.shape
     q, w, k, v, a, b = [i.view(B, T, HC // 64, 64) for i in [q, w, k, v, a, b]]
+    if recompute_state:
+        return WindBackstepping.apply(w, q, k, v, a, b, True).view(B, T, HC)
     return WindBackstepping.apply(w, q, k, v, a, b).view(B, T, HC)
 
 
@@ -293,11 +283,12 @@ def wkv7_forward_state(w, q, k, v, z, a, state0=None, want_state=True, s_ckpt=No
     s_fin = torch.empty(B, H, HEAD_SIZE, HEAD_SIZE, dtype=torch.float32, device=w.device) if want_state else None
     lib = hip_lib.load()
     with torch.cuda.device(w.device):
-        rc = lib.vrwkv_wkv7_forward_state_bf16(B, T, H, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), z.data_ptr(),
-                                               a.data_ptr(), y.data_ptr(), state0.data_ptr() if state0 is not None else 0,
-                                               s_fin.data_ptr() if want_state else 0,
-                                               s_ckpt.data_ptr() if s_ckpt is not None else 0, sa.data_ptr() if sa is not None else 0,
-                                               torch.cuda.current_stream(w.device).cuda_stream)
+        stream = torch.cuda.current_stream(w.device).cuda_stream
+        rc = _timed("fwd_state", B * T * H * HEAD_SIZE, w.device, lambda: lib.vrwkv_wkv7_forward_state_bf16(
+            B, T, H, w.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), z.data_ptr(),
+            a.data_ptr(), y.data_ptr(), state0.data_ptr() if state0 is not None else 0,
+            s_fin.data_ptr() if want_state else 0,
+            s_ckpt.data_ptr() if s_ckpt is not None else 0, sa.data_ptr() if sa is not None else 0, stream))
     hip_lib.check(rc, "vrwkv_wkv7_forward_state_bf16")
     return y, s_fin
 
