@@ -15,7 +15,7 @@
 namespace wkv7exp {
 using namespace wkv7launch;
 
-inline bool is_experiment(int var) { return var == 7 || var == 10 || var == 11 || (var > 60 && var < 68) || (var > 70 && var < 78) || (var > 80 && var < 89); }
+inline bool is_experiment(int var) { return var == 7 || var == 10 || var == 11 || (var >= 20 && var <= 29) || (var > 60 && var < 68) || (var > 70 && var < 78) || (var > 80 && var < 89); }
 
 inline int launch(int var, dim3 grid, hipStream_t st, const wkv7::BwdArgs& p) {
     void (*kern)(wkv7::BwdArgs) = nullptr;
@@ -24,6 +24,11 @@ inline int launch(int var, dim3 grid, hipStream_t st, const wkv7::BwdArgs& p) {
         case 7: kern = &wkv7v7::bwd_kernel_v7<false>; lds = sizeof(wkv7v7::LdsV7); break;
         case 10: kern = &wkv7v8::bwd_kernel_v8<false, VRWKV_V8_PI, VRWKV_V8_PJ, VRWKV_V8_PP, 0, true, VRWKV_V8_PP, true, true>; break;
         case 11: kern = &wkv7v8::bwd_kernel_v8<false, VRWKV_V8_PI, VRWKV_V8_PJ, VRWKV_V8_PP, 0, true, VRWKV_V8_PP, false, true>; break;
+        // round 6: variant 9 with OPT bits (wkv7_bwd_v8.h): 21 dealt tile-pair reads, 22 swizzled dS image, 23 both; timing only (garbage results): 24 no tail
+        // stores, 25 no S0 requests, 26 neither
+#define VRWKV_OPT_CASE(v, o) case v: kern = &wkv7v8::bwd_kernel_v8<false, VRWKV_V8_PI, VRWKV_V8_PJ, VRWKV_V8_PP, 0, true, VRWKV_V8_PP, true, false, o>; break;
+        VRWKV_OPT_CASE(20, 0) VRWKV_OPT_CASE(21, 1) VRWKV_OPT_CASE(22, 2) VRWKV_OPT_CASE(23, 3) VRWKV_OPT_CASE(24, 64) VRWKV_OPT_CASE(25, 128) VRWKV_OPT_CASE(26, 192)
+#undef VRWKV_OPT_CASE
 #define VRWKV_ROLE_CASES(base, KERN, LDS, ...)                                                        \
         case base + 1: kern = &KERN<false, __VA_ARGS__ 1>; lds = sizeof(LDS); break;   /* no P */        \
         case base + 2: kern = &KERN<false, __VA_ARGS__ 2>; lds = sizeof(LDS); break;   /* no I */        \

@@ -51,6 +51,8 @@ int emu_wkv7_backward_chunked(int B, int T, int H, const void* w, const void* q,
     if (mode == 10) { emu::launch(grid, dim3(768), [&] { wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, true>(p); }); return (int)sizeof(wkv7v8::LdsV8); }   // + score pieces a step ahead on the P waves
     if (mode == 11) { emu::launch(grid, dim3(768), [&] { wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, false, true>(p); }); return (int)sizeof(wkv7v8::LdsV8); }  // tail on the J waves
     if (mode == 12) { emu::launch(grid, dim3(768), [&] { wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, true, true>(p); }); return (int)sizeof(wkv7v8::LdsV8); }   // + score pieces a step ahead
+    if (mode == 13) { emu::launch(grid, dim3(768), [&] { wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, true, false, 3>(p); }); return (int)sizeof(wkv7v8::LdsV8); }   // variant 9 + dealt tile-pair reads + swizzled dS image
+    if (mode == 14) { emu::launch(grid, dim3(768), [&] { wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, false, false, 3>(p); }); return (int)sizeof(wkv7v8::LdsV8); }   // variant 8 + the same
     return -1;
 }
 

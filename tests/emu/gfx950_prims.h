@@ -214,7 +214,21 @@ DEVFN f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return d;
 }
 
-DEVFN char* dyn_lds() { static __attribute__((aligned(16))) char buf[160 * 1024]; return buf; }
+DEVFN char* dyn_lds() { static __attribute__((aligned(256))) char buf[160 * 1024]; return buf; }
+#ifdef EMU_LDS_TRACE
+#include <vector>
+namespace emu {
+struct LdsRec { uint32_t off; uint16_t tid; uint16_t kind; void* pc; };
+inline std::vector<LdsRec>& lds_recs() { static std::vector<LdsRec> v; return v; }
+inline bool& lds_trace_on() { static bool on = false; return on; }
+inline void lds_trace(int kind, const void* p, void* pc) {
+    if (!lds_trace_on() || !blk()) return;
+    const char* b = dyn_lds();
+    if ((const char*)p < b || (const char*)p >= b + 160 * 1024) return;       // global memory / stack
+    lds_recs().push_back(LdsRec{(uint32_t)((const char*)p - b), (uint16_t)flat_tid(), (uint16_t)kind, pc});
+}
+}  // namespace emu
+#endif
 // LDS "addresses" as 32-bit values: offsets from the start of the (single) dynamic LDS array
 DEVFN unsigned lds_addr_u32(const void* lds_ptr) { return (unsigned)((const char*)lds_ptr - dyn_lds()); }
 DEVFN char* emu_lds_from_u32(unsigned a) { return dyn_lds() + a; }
@@ -226,6 +240,7 @@ DEVFN void block_sync() { emu::block_barrier(); }
 DEVFN void block_sync_lds() { emu::block_barrier(); }
 DEVFN void wave_lds_fence() { emu::wave_barrier(); }
 DEVFN uint2 lds_read_tr16(const uint16_t* p) {
+    VRWKV_LDS_TRACE(3, p)
     int me = emu::flat_tid(), wb = emu::wave_base(), l = me & 63;
     uint16_t* s = (uint16_t*)emu::slot(me);
     for (int e = 0; e < 4; ++e) s[e] = p[e];
@@ -239,13 +254,15 @@ DEVFN uint2 lds_read_tr16(const uint16_t* p) {
     r.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
     return r;
 }
-DEVFN void lds_dma16(const void* gsrc, void* lds_wave_base) { memcpy((char*)lds_wave_base + 16 * (emu::flat_tid() & 63), gsrc, 16); }
+DEVFN void lds_dma16(const void* gsrc, void* lds_wave_base) { VRWKV_LDS_TRACE(7, (char*)lds_wave_base + 16 * (emu::flat_tid() & 63)) memcpy((char*)lds_wave_base + 16 * (emu::flat_tid() & 63), gsrc, 16); }
 DEVFN void lds_dma16_sbase(const void* uniform_base, unsigned lane_byte_off, void* lds_wave_base) {
+    VRWKV_LDS_TRACE(7, (char*)lds_wave_base + 16 * (emu::flat_tid() & 63))
     memcpy((char*)lds_wave_base + 16 * (emu::flat_tid() & 63), (const char*)uniform_base + lane_byte_off, 16);
 }
 DEVFN char* emu_lds_from_u32(unsigned a);
 DEVFN const void* uniform_ptr(const void* ptr) { return ptr; }
 template <int IMM> DEVFN void lds_dma16_lean(const void* uniform_base, unsigned lane_byte_off, unsigned lds_dst_uniform) {
+    VRWKV_LDS_TRACE(7, emu_lds_from_u32(lds_dst_uniform) + IMM + 16 * (emu::flat_tid() & 63))
     memcpy(emu_lds_from_u32(lds_dst_uniform) + IMM + 16 * (emu::flat_tid() & 63), (const char*)uniform_base + lane_byte_off + IMM, 16);   // the immediate moves both ends
 }
 template <int N_> DEVFN void vmem_wait() {}

@@ -22,9 +22,30 @@ struct dim3 {
 struct emu_uint3 { unsigned x, y, z; };
 struct uint4 { uint32_t x, y, z, w; };
 struct uint2 { uint32_t x, y; };
+#ifdef EMU_LDS_TRACE
+// LDS bank-conflict tracer (benchmarks/lds_conflicts.py): kinds 0 read_b32 1 read_b64 2 read_b128 3 read_b64_tr_b16 4 write_b32 5 write_b64
+// 6 write_b128 7 LDS-DMA landing (16 B per lane).  Sites are code addresses (symbolised afterwards from the -g build).
+namespace emu { inline void lds_trace(int kind, const void* p, void* pc); }
+#define EMU_PC() ({ void* pc_; asm volatile("lea 0(%%rip), %0" : "=r"(pc_)); pc_; })
+#define VRWKV_LDS_TRACE(kind, ptr) emu::lds_trace(kind, ptr, EMU_PC());
+struct float4 {
+    float x, y, z, w;
+    float4() = default;
+    float4(float a, float b, float c, float d) : x(a), y(b), z(c), w(d) {}
+    __attribute__((always_inline)) float4(const float4& o) : x(o.x), y(o.y), z(o.z), w(o.w) { emu::lds_trace(2, &o, EMU_PC()); }
+    __attribute__((always_inline)) float4& operator=(const float4& o) {
+        emu::lds_trace(2, &o, EMU_PC());
+        emu::lds_trace(6, this, EMU_PC());
+        x = o.x; y = o.y; z = o.z; w = o.w;
+        return *this;
+    }
+};
+#else
+#define VRWKV_LDS_TRACE(kind, ptr)
 struct float4 { float x, y, z, w; };
+#endif
 struct float2 { float x, y; };
-static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+static inline float4 make_float4(float a, float b, float c, float d) { return float4(a, b, c, d); }
 static inline float2 make_float2(float a, float b) { return float2{a, b}; }
 static inline uint4 make_uint4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return uint4{a, b, c, d}; }
 static inline uint2 make_uint2(uint32_t a, uint32_t b) { return uint2{a, b}; }

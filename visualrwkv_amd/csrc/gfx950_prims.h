@@ -162,6 +162,8 @@ DEVFN f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin
 // All LDS of a kernel that needs more than the 64 KB static limit lives in this one array.
 extern __shared__ __attribute__((aligned(16))) char vrwkv_dyn_lds[];
 DEVFN char* dyn_lds() { return vrwkv_dyn_lds; }
+// Hook of the host emulator's LDS bank-conflict tracer (benchmarks/lds_conflicts.py); nothing on the device.
+#define VRWKV_LDS_TRACE(kind, ptr)
 
 // static wave priority (0..3); scalar, ignores EXEC: call only under wave-uniform control flow
 template <int P> DEVFN void wave_priority() { __builtin_amdgcn_s_setprio(P); }

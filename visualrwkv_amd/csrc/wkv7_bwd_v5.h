@@ -85,9 +85,10 @@ struct LdsV5 {
 static_assert(sizeof(LdsV5) <= 160 * 1024, "LDS budget");
 
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
-DEVFN bf16x8 ld16(const uint16_t* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(p)); }
+DEVFN bf16x8 ld16(const uint16_t* p) { VRWKV_LDS_TRACE(2, p) return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(p)); }
 DEVFN void st16(uint16_t* p, uint2 a, uint2 b) {
     u32x4v v = {a.x, a.y, b.x, b.y};
+    VRWKV_LDS_TRACE(6, p)
     *reinterpret_cast<u32x4v*>(p) = v;
 }
 DEVFN f32x4 mfma32(bf16x8 x, bf16x8 y, f32x4 acc) { return mfma_16x16x32_bf16(x, y, acc); }

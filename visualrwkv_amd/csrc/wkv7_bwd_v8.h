@@ -23,6 +23,9 @@
 #include <wkv7_chunked.h>
 #include <wkv7_bwd_rows.h>     // ChunkImg7, RawP, DmaLane, dma_lane, prep7, dscores-style helpers; through it v6 / v5 building blocks
 
+#ifndef VRWKV_V8_OPT
+#define VRWKV_V8_OPT 0
+#endif
 #ifndef VRWKV_V8_ROTATE
 #define VRWKV_V8_ROTATE 1
 #endif
@@ -91,6 +94,10 @@ using wkv7v7::read_stage;
 using wkv7v7::tail7;
 using wkv7v7::dscores7;
 constexpr int SIMG = N * N;           // elements of a [64][64] image
+// element offset in the [64][64] bf16 dS image: img_off, or (SWZ) with bit 3 of the row folded into the slot swizzle
+template <bool SWZ> DEVFN int dsi_off(int row, int col) {
+    return SWZ ? row * 64 + ((((col >> 3) ^ (row & 7) ^ ((row >> 1) & 4)) << 3) | (col & 7)) : img_off(row, col);
+}
 struct LdsV8 {
     ChunkImg7 b[3];
     uint16_t vdy[4][2][IMG];         // V, dY [t][i] of chunk c in slot c & 3, written by LDS-DMA (swizzled like every image)
@@ -199,6 +206,7 @@ DEVFN Prep8 prep8(ChunkImg7& B, const RawP& raw, int c16, int j0, const LaneAddr
     if (c16 == 15) *reinterpret_cast<float4*>(&B.cl[j0]) = make_float4(o.cc[0], o.cc[1], o.cc[2], o.cc[3]);
     return o;
 }
+template <bool NOSTORE = false>
 DEVFN void tail8(LdsV8& lds, int par, const TailQ& tr, const BwdArgs& p, size_t u, unsigned lane_boff, int c16, int pw, int g, const LaneAddr& la) {
     const float4 zt4 = *reinterpret_cast<const float4*>(&lds.res[0][la.f32]);
     const float4 qt4 = *reinterpret_cast<const float4*>(&lds.res[1][la.f32]);
@@ -224,6 +232,10 @@ DEVFN void tail8(LdsV8& lds, int par, const TailQ& tr, const BwdArgs& p, size_t 
         dw[e] = gt * (l2 * LN2);
     }
     auto out = [&](uint16_t* base) { return reinterpret_cast<uint2*>(reinterpret_cast<char*>(base + u) + lane_boff); };   // uniform base + lane offset
+    if (NOSTORE) {          // timing experiment: the results stay "used" (an LDS write nobody reads) but never leave the chip
+        lds.glast[par][16 * pw + 4 * g] = dw[0] + dq[1] + dk[2] + dz[3] + da[0];
+        return;
+    }
     *out(p.dw) = make_uint2(cvt_pk_bf16(dw[0], dw[1]), cvt_pk_bf16(dw[2], dw[3]));
     *out(p.dq) = make_uint2(cvt_pk_bf16(dq[0], dq[1]), cvt_pk_bf16(dq[2], dq[3]));
     *out(p.dk) = make_uint2(cvt_pk_bf16(dk[0], dk[1]), cvt_pk_bf16(dk[2], dk[3]));
@@ -289,7 +301,13 @@ DEVFN void jtail_run(const JTailIn& t, const LdsV8& lds, int cj, const BwdArgs& 
 // slack (profiles/r4b_wkv7_phases_waves_v8_ahead.jsonl).  The tail is ~165 of them.  On the J waves it needs Zt Qt Ah Kh of the chunk
 // (hi + lo from the operand images: dq q = dQt Qt etc., so the raw inputs are not needed) and log2 c_t (the P waves leave it in a
 // ring of three fp32 images that takes the place of `res`): no three-deep register queue on the P waves, no `res` round trip, no flag 4.
-template <bool PROF, int PI = VRWKV_V8_PI, int PJ = VRWKV_V8_PJ, int PP = VRWKV_V8_PP, int SKIP = 0, bool TBF16 = true, int PT = PP, bool AHEAD = false, bool JTAIL = false>
+// OPT (bit mask): 1 = the dS update's transposing reads of tile pairs are dealt so that an instruction touches both halves of its 16-byte slots
+// (rows 4g, 4g+1 of one tile and rows 4g+2, 4g+3 of its neighbour: each of the two reads of a pair returns half of either tile, re-paired in
+// registers for free) -- as two reads of the SAME half they were 2-way bank conflicts by construction (benchmarks/lds_conflicts.py: 128 of the
+// workgroup's 536 conflict cycles per step); 2 = the dS image for the J waves is swizzled with (row & 7) ^ ((row >> 1) & 4), which keeps the
+// I waves' 16-byte writes conflict-free and makes the J waves' transposing reads of rows r and r + 8 land on different banks (64 cycles per step);
+// 64 / 128 (timing experiments only, results are garbage): no tail stores / no S0 requests
+template <bool PROF, int PI = VRWKV_V8_PI, int PJ = VRWKV_V8_PJ, int PP = VRWKV_V8_PP, int SKIP = 0, bool TBF16 = true, int PT = PP, bool AHEAD = false, bool JTAIL = false, int OPT = VRWKV_V8_OPT>
 __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
     LdsV8& lds = *reinterpret_cast<LdsV8*>(dyn_lds());
     const int T = p.T, H = p.H;
@@ -368,12 +386,13 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                 // S0 of chunk cd = s[cd-1] for the j-split of the next step, into the image the J waves have just left
                 {
                     const int k0 = w == 1 ? 0 : w == 2 ? 5 : 10, k1 = w == 0 ? 0 : w == 1 ? 5 : w == 2 ? 10 : 16;      // waves 1-3: 5 5 6 KB
-                    if (FULL) {
+                    if (OPT & 128) {
+                    } else if (FULL) {
                         const float* sc = sbase + (size_t)(cd - 1) * N * N;
                         if (w == 1) s0_lean<0>(lds, sc, ll); else if (w == 2) s0_lean<1>(lds, sc, ll); else if (w == 3) s0_lean<2>(lds, sc, ll);
                     } else if (cd >= 0 && cd <= nchunk - 1) dma_state(lds.s0, cd > 0 ? sbase + (size_t)(cd - 1) * N * N : nullptr, k0, k1, lane);
                 }
-                if (!JTAIL && (FULL || (ct >= 0 && ct <= nchunk - 1))) tail8(lds, ct & 1, qt, p, head_base + (size_t)ct * L * ts, lane_boff, c16, w, g, la);
+                if (!JTAIL && (FULL || (ct >= 0 && ct <= nchunk - 1))) tail8<(OPT & 64) != 0>(lds, ct & 1, qt, p, head_base + (size_t)ct * L * ts, lane_boff, c16, w, g, la);
                 WKV_STAMP(0)
                 if (SHIFT && !JTAIL) { q2 = q1; q1 = q0; }
                 TailQ& qn = SHIFT ? q0 : qt;
@@ -398,7 +417,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                     wkv7v6::scores6<true>(lds, lds.b[cp % 3], w, c16, g, la);
                 }
                 WKV_STAMP(1)
-                if (FULL && !JTAIL) vmem_wait<5>(); else vmem_drain();      // JTAIL: this role issues requests only
+                if (FULL && !JTAIL && !(OPT & 64)) vmem_wait<5>(); else vmem_drain();      // JTAIL: this role issues requests only
             } else if (w == 0 && cd >= 0 && cd <= nchunk - 1) lds_flag_add(&lds.flag[2]);
             WKV_STAMP(2)
             block_sync_lds();
@@ -426,8 +445,11 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
 #pragma unroll
         for (int x = 0; x < 4; ++x) dS1[x] = zero4();
         unsigned n_sc = 0, n_t = 0;
-        const int img_row = img_off(16 * w + c16, 8 * g);   // this lane's 16-byte piece of the dS image, k block 0 (+ 32 columns: block 1)
-        const int img_row1 = img_off(16 * w + c16, 32 + 8 * g);
+        const int img_row = dsi_off<(OPT & 2) != 0>(16 * w + c16, 8 * g);   // this lane's 16-byte piece of the dS image, k block 0 (+ 32 columns: block 1)
+        const int img_row1 = dsi_off<(OPT & 2) != 0>(16 * w + c16, 32 + 8 * g);
+        // OPT & 1: transposing reads of a tile pair, dealt over both halves of the 16-byte slots (see the template comment)
+        const int hb4 = 4 * ((c16 >> 3) & 1);
+        const int tra[2] = {la.tri[0] + hb4, la.tri[1] + hb4}, trb[2] = {la.tri[0] + 4 - hb4, la.tri[1] + 4 - hb4};
         for (int n = 0; n < nsteps; ++n) {
             const int ci = nchunk - n, cj = ci + 1;         // this role's chunk | the J waves' chunk of this step
             WKV_STAMP(4)
@@ -560,16 +582,38 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                 WKV_STAMP(6)
                 // dS^T <- diag(c_L) dS^T + [Qt^T | Zt^T] [dY ; dR]
                 const bf16x8 y1 = mk8(dyv, rh), y2 = mk8(0u, 0u, rl.x, rl.y);
+                if (OPT & 1) {
 #pragma unroll
-                for (int jb = 0; jb < 4; ++jb) {
-                    f32x4 acc = dSc[jb];
-                    const int o = la.tri[jb >> 1] + 4 * (jb & 1);
-                    const bf16x8 xh8 = mk8(lds_read_tr16(&B.opnd[2][o]), lds_read_tr16(&B.opnd[0][o]));
-                    const bf16x8 xl8 = mk8(lds_read_tr16(&B.opnd[3][o]), lds_read_tr16(&B.opnd[1][o]));
-                    acc = mfma32(xh8, y1, acc);
-                    acc = mfma32(xl8, y1, acc);
-                    acc = mfma32(xh8, y2, acc);
-                    dS1[jb] = acc;
+                    for (int pr = 0; pr < 2; ++pr) {
+                        // read A: rows 4g, 4g+1 of the even tile | rows 4g+2, 4g+3 of the odd one; read B: the complement
+                        const uint2 qha = lds_read_tr16(&B.opnd[2][tra[pr]]), qhb = lds_read_tr16(&B.opnd[2][trb[pr]]);
+                        const uint2 zha = lds_read_tr16(&B.opnd[0][tra[pr]]), zhb = lds_read_tr16(&B.opnd[0][trb[pr]]);
+                        const uint2 qla = lds_read_tr16(&B.opnd[3][tra[pr]]), qlb = lds_read_tr16(&B.opnd[3][trb[pr]]);
+                        const uint2 zla = lds_read_tr16(&B.opnd[1][tra[pr]]), zlb = lds_read_tr16(&B.opnd[1][trb[pr]]);
+#pragma unroll
+                        for (int od = 0; od < 2; ++od) {
+                            const int jb = 2 * pr + od;
+                            f32x4 acc = dSc[jb];
+                            const bf16x8 xh8 = od ? mk8(qhb.x, qha.y, zhb.x, zha.y) : mk8(qha.x, qhb.y, zha.x, zhb.y);
+                            const bf16x8 xl8 = od ? mk8(qlb.x, qla.y, zlb.x, zla.y) : mk8(qla.x, qlb.y, zla.x, zlb.y);
+                            acc = mfma32(xh8, y1, acc);
+                            acc = mfma32(xl8, y1, acc);
+                            acc = mfma32(xh8, y2, acc);
+                            dS1[jb] = acc;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int jb = 0; jb < 4; ++jb) {
+                        f32x4 acc = dSc[jb];
+                        const int o = la.tri[jb >> 1] + 4 * (jb & 1);
+                        const bf16x8 xh8 = mk8(lds_read_tr16(&B.opnd[2][o]), lds_read_tr16(&B.opnd[0][o]));
+                        const bf16x8 xl8 = mk8(lds_read_tr16(&B.opnd[3][o]), lds_read_tr16(&B.opnd[1][o]));
+                        acc = mfma32(xh8, y1, acc);
+                        acc = mfma32(xl8, y1, acc);
+                        acc = mfma32(xh8, y2, acc);
+                        dS1[jb] = acc;
+                    }
                 }
             }
             WKV_STAMP(2)
@@ -589,7 +633,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) tro[kb][h] = img_off(32 * kb + 8 * g + 4 * h + (c16 >> 2), 16 * w + 4 * (c16 & 3));
+        for (int h = 0; h < 2; ++h) tro[kb][h] = dsi_off<(OPT & 2) != 0>(32 * kb + 8 * g + 4 * h + (c16 >> 2), 16 * w + 4 * (c16 & 3));
     bf16x8 s0h_p[2] = {mk8(0u, 0u, 0u, 0u), mk8(0u, 0u, 0u, 0u)}, s0l_p[2] = {mk8(0u, 0u, 0u, 0u), mk8(0u, 0u, 0u, 0u)};   // S0 operands of the previous step = S_L of this one
     unsigned n_dm = 0;
     JTailIn jt{};                                       // JTAIL: results and tail inputs of the chunk of the previous step

@@ -36,8 +36,8 @@ DEVFN f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 
 struct RawChunk { uint2 w, q, k, z, a, v; };
 
-DEVFN uint2 ld8(const uint16_t* p) { return *reinterpret_cast<const uint2*>(p); }
-DEVFN void st8(uint16_t* p, uint2 v) { *reinterpret_cast<uint2*>(p) = v; }
+DEVFN uint2 ld8(const uint16_t* p) { VRWKV_LDS_TRACE(1, p) return *reinterpret_cast<const uint2*>(p); }
+DEVFN void st8(uint16_t* p, uint2 v) { VRWKV_LDS_TRACE(5, p) *reinterpret_cast<uint2*>(p) = v; }
 
 // split 4 consecutive values -> packed hi (2 dwords) and lo (2 dwords)
 DEVFN void split4(const float* x, uint2& hi, uint2& lo) {
