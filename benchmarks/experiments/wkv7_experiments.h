@@ -9,25 +9,29 @@
 #pragma once
 #include <wkv7_launch.h>
 #include <wkv7_bwd_v6.h>
+#include <wkv7_bwd_v6_kernel.h>     // the round-3 kernel (variant 6)
 #include <wkv7_bwd_v7.h>
-#include <wkv7_bwd_v8.h>
+#include <wkv7_bwd_v8x.h>     // the v8 kernel WITH its knobs (namespace wkv7v8x); the product's wkv7_bwd_v8.h has none
 
 namespace wkv7exp {
 using namespace wkv7launch;
 
-inline bool is_experiment(int var) { return var == 7 || var == 10 || var == 11 || (var >= 20 && var <= 29) || (var > 60 && var < 68) || (var > 70 && var < 78) || (var > 80 && var < 89); }
+inline bool is_experiment(int var) { return var == 6 || var == 7 || var == 10 || var == 11 || (var >= 20 && var <= 39) || (var > 60 && var < 68) || (var > 70 && var < 78) || (var > 80 && var < 89); }
 
 inline int launch(int var, dim3 grid, hipStream_t st, const wkv7::BwdArgs& p) {
     void (*kern)(wkv7::BwdArgs) = nullptr;
-    size_t lds = sizeof(wkv7v8::LdsV8);
+    size_t lds = sizeof(wkv7v8x::LdsV8);
     switch (var) {
+        case 6: kern = &wkv7v6::bwd_kernel_v6<false>; lds = sizeof(wkv7v6::LdsV6); break;
         case 7: kern = &wkv7v7::bwd_kernel_v7<false>; lds = sizeof(wkv7v7::LdsV7); break;
-        case 10: kern = &wkv7v8::bwd_kernel_v8<false, VRWKV_V8_PI, VRWKV_V8_PJ, VRWKV_V8_PP, 0, true, VRWKV_V8_PP, true, true>; break;
-        case 11: kern = &wkv7v8::bwd_kernel_v8<false, VRWKV_V8_PI, VRWKV_V8_PJ, VRWKV_V8_PP, 0, true, VRWKV_V8_PP, false, true>; break;
+        case 10: kern = &wkv7v8x::bwd_kernel_v8<false, VRWKV_V8_PI, VRWKV_V8_PJ, VRWKV_V8_PP, 0, true, VRWKV_V8_PP, true, true>; break;
+        case 11: kern = &wkv7v8x::bwd_kernel_v8<false, VRWKV_V8_PI, VRWKV_V8_PJ, VRWKV_V8_PP, 0, true, VRWKV_V8_PP, false, true>; break;
         // round 6: variant 9 with OPT bits (wkv7_bwd_v8.h): 21 dealt tile-pair reads, 22 swizzled dS image, 23 both; timing only (garbage results): 24 no tail
-        // stores, 25 no S0 requests, 26 neither
-#define VRWKV_OPT_CASE(v, o) case v: kern = &wkv7v8::bwd_kernel_v8<false, VRWKV_V8_PI, VRWKV_V8_PJ, VRWKV_V8_PP, 0, true, VRWKV_V8_PP, true, false, o>; break;
-        VRWKV_OPT_CASE(20, 0) VRWKV_OPT_CASE(21, 1) VRWKV_OPT_CASE(22, 2) VRWKV_OPT_CASE(23, 3) VRWKV_OPT_CASE(24, 64) VRWKV_OPT_CASE(25, 128) VRWKV_OPT_CASE(26, 192)
+        // stores, 25 no S0 requests, 26 neither; 27 S0 by register prefetch in the J waves, 28 = 27 + 23, 29 = 27 without tail stores (timing only)
+#define VRWKV_OPT_CASE(v, o) case v: kern = &wkv7v8x::bwd_kernel_v8<false, VRWKV_V8_PI, VRWKV_V8_PJ, VRWKV_V8_PP, 0, true, VRWKV_V8_PP, true, false, o>; break;
+        VRWKV_OPT_CASE(20, 0) VRWKV_OPT_CASE(21, 1) VRWKV_OPT_CASE(22, 2) VRWKV_OPT_CASE(23, 3) VRWKV_OPT_CASE(24, 64) VRWKV_OPT_CASE(25, 128) VRWKV_OPT_CASE(26, 192) VRWKV_OPT_CASE(27, 4) VRWKV_OPT_CASE(28, 20) VRWKV_OPT_CASE(29, 4 + 64)
+        // cache policy of the requests (rows: bits 8-9, S0: bits 10-11; 1 nt, 2 sc1, 3 sc0 sc1 nt) and non-temporal tail stores (4096)
+        VRWKV_OPT_CASE(30, 256) VRWKV_OPT_CASE(31, 1024) VRWKV_OPT_CASE(32, 1280) VRWKV_OPT_CASE(33, 2048) VRWKV_OPT_CASE(34, 3072) VRWKV_OPT_CASE(35, 4096) VRWKV_OPT_CASE(36, 4096 + 1280) VRWKV_OPT_CASE(37, 512 + 2048)
 #undef VRWKV_OPT_CASE
 #define VRWKV_ROLE_CASES(base, KERN, LDS, ...)                                                        \
         case base + 1: kern = &KERN<false, __VA_ARGS__ 1>; lds = sizeof(LDS); break;   /* no P */        \
@@ -39,9 +43,9 @@ inline int launch(int var, dim3 grid, hipStream_t st, const wkv7::BwdArgs& p) {
         case base + 7: kern = &KERN<false, __VA_ARGS__ 7>; lds = sizeof(LDS); break;   /* barriers only */
         VRWKV_ROLE_CASES(60, wkv7v6::bwd_kernel_v6, wkv7v6::LdsV6, 0, 0, 1, false, true,)
         VRWKV_ROLE_CASES(70, wkv7v7::bwd_kernel_v7, wkv7v7::LdsV7, 0, 0, 1,)
-        VRWKV_ROLE_CASES(80, wkv7v8::bwd_kernel_v8, wkv7v8::LdsV8, 0, 0, 1,)
+        VRWKV_ROLE_CASES(80, wkv7v8x::bwd_kernel_v8, wkv7v8x::LdsV8, 0, 0, 1,)
 #undef VRWKV_ROLE_CASES
-        case 88: kern = &wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 8>; break;     // everything but the T chain (P wave 0 only raises its flag)
+        case 88: kern = &wkv7v8x::bwd_kernel_v8<false, 0, 0, 1, 8>; break;     // everything but the T chain (P wave 0 only raises its flag)
         default: return VRWKV_EINVAL;
     }
     return launch_lds(kern, grid, dim3(768), lds, st, p);

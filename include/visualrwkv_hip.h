@@ -190,15 +190,17 @@ int vrwkv_wkv7_step_bf16(int B, int H, const void* w, const void* q, const void*
  * forward:  -1 = the default: csrc/wkv7_fwd_v4.h (chunked MFMA kernel with producer / consumer waves; rows in by LDS-DMA, results out
  *            through LDS images, 1 KB per store instruction) for B*H > 128, else the two-workgroups-per-head instantiation of
  *            csrc/wkv7_fwd_v3.h; 7 = wkv7_fwd_v4.h whatever the size; 1..5 = instantiations of wkv7_fwd_v3.h for A/B (4 = its default one).
- * backward: -1 = the default (9 for B x H > 256, else 8; tensors of 4 GiB and more: 6), 9 = 8 with the score pieces of a chunk formed one step ahead by the
+ * backward: -1 = the default (9 for B x H > 256, else 8; a launch whose `sa` reaches 4 GiB runs as batch slices of the same kernel), 9 = 8 with the score pieces of a chunk formed one step ahead by the
  *            memory-role waves in what was their barrier wait (0 ... -3 % against 8 at B = 4 ... 32, -2.3 % inside the training step), 8 = three-role
  *            pipeline of 12 waves with ONE copy of dL/dS (handed from the i-split to the j-split waves as an operand image), the T chain on a
- *            memory-role wave and a memory role that moves full 128-byte rows by LDS-DMA (csrc/wkv7_bwd_v8.h, wkv7_bwd_rows.h), 6 = three-stage wave
- *            pipeline with 8-byte-per-lane register loads (csrc/wkv7_bwd_v6.h), 5 = producer / consumer schedule of 8 waves (csrc/wkv7_bwd_v5.h; also
- *            the sequence-parallel kernel).  Anything else: VRWKV_EINVAL (experiment builds of benchmarks/build_alt.sh accept more:
- *            benchmarks/experiments/wkv7_experiments.h). */
+ *            memory-role wave and a memory role that moves full 128-byte rows by LDS-DMA (csrc/wkv7_bwd_v8.h, wkv7_bwd_rows.h), 5 = producer / consumer schedule of
+ *            8 waves (csrc/wkv7_bwd_v5.h; also the sequence-parallel kernel, and the kernel of a single sample of 4 GiB and more).  Anything else:
+ *            VRWKV_EINVAL (experiment builds of benchmarks/build_alt.sh accept more: benchmarks/experiments/wkv7_experiments.h). */
 int vrwkv_wkv7_set_forward_variant(int variant);
 int vrwkv_wkv7_set_backward_variant(int variant);
+/* Test hook: the tensor size (bytes of the fp32 `sa`, B*T*H*64*4) from which vrwkv_wkv7_backward_bf16 cuts a launch into batch slices (the default
+ * kernel forms 32-bit byte offsets inside a tensor); 0 = the default, 4 GiB.  Results do not depend on it. */
+int vrwkv_wkv7_set_backward_slice_limit(unsigned long long bytes);
 /* The kernel generation the LAST vrwkv_wkv7_forward_bf16 (backward == 0) / vrwkv_wkv7_backward_bf16 (backward != 0) launch of this
  * process resolved to, in the numbering above (forward: 7 = wkv7_fwd_v4.h, 6 = two workgroups per head, 4 = wkv7_fwd_v3.h; 0 = none yet);
  * vrwkv_wkv7_forward_state_bf16 records into the forward slot as well.  Lets a single-threaded parity test assert WHICH kernel the default

@@ -6,8 +6,10 @@
 #include <wkv7_fwd_v3.h>
 #include <wkv7_fwd_v4.h>
 #include <wkv7_bwd_v6.h>
+#include <wkv7_bwd_v6_kernel.h>   // benchmarks/experiments (the round-3 kernel, A/B partner; kept lane-exact here)
 #include <wkv7_bwd_v7.h>   // benchmarks/experiments (A/B partner; kept lane-exact here)
 #include <wkv7_bwd_v8.h>
+#include <wkv7_bwd_v8x.h>  // benchmarks/experiments: the v8 kernel with its knobs (JTAIL, OPT bits; kept lane-exact here)
 #include <wkv7_bwd_v5.h>
 #include <wkv6_chunked.h>
 #include <wkv6_bwd_v2.h>
@@ -48,11 +50,13 @@ int emu_wkv7_backward_chunked(int B, int T, int H, const void* w, const void* q,
     if (mode == 7) { emu::launch(grid, dim3(768), [&] { wkv7v6::bwd_kernel_v6<false>(p); }); return (int)sizeof(wkv7v6::LdsV6); }   // three-stage wave pipeline
     if (mode == 8) { emu::launch(grid, dim3(768), [&] { wkv7v7::bwd_kernel_v7<false>(p); }); return (int)sizeof(wkv7v7::LdsV7); }   // + full-row memory role
     if (mode == 9) { emu::launch(grid, dim3(768), [&] { wkv7v8::bwd_kernel_v8<false>(p); }); return (int)sizeof(wkv7v8::LdsV8); }   // one copy of dS, T on P wave 0
-    if (mode == 10) { emu::launch(grid, dim3(768), [&] { wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, true>(p); }); return (int)sizeof(wkv7v8::LdsV8); }   // + score pieces a step ahead on the P waves
-    if (mode == 11) { emu::launch(grid, dim3(768), [&] { wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, false, true>(p); }); return (int)sizeof(wkv7v8::LdsV8); }  // tail on the J waves
-    if (mode == 12) { emu::launch(grid, dim3(768), [&] { wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, true, true>(p); }); return (int)sizeof(wkv7v8::LdsV8); }   // + score pieces a step ahead
-    if (mode == 13) { emu::launch(grid, dim3(768), [&] { wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, true, false, 3>(p); }); return (int)sizeof(wkv7v8::LdsV8); }   // variant 9 + dealt tile-pair reads + swizzled dS image
-    if (mode == 14) { emu::launch(grid, dim3(768), [&] { wkv7v8::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, false, false, 3>(p); }); return (int)sizeof(wkv7v8::LdsV8); }   // variant 8 + the same
+    if (mode == 10) { emu::launch(grid, dim3(768), [&] { wkv7v8::bwd_kernel_v8<false, true>(p); }); return (int)sizeof(wkv7v8::LdsV8); }   // + score pieces a step ahead on the P waves
+    if (mode == 11) { emu::launch(grid, dim3(768), [&] { wkv7v8x::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, false, true>(p); }); return (int)sizeof(wkv7v8x::LdsV8); }  // tail on the J waves
+    if (mode == 12) { emu::launch(grid, dim3(768), [&] { wkv7v8x::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, true, true>(p); }); return (int)sizeof(wkv7v8x::LdsV8); }   // + score pieces a step ahead
+    if (mode == 13) { emu::launch(grid, dim3(768), [&] { wkv7v8x::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, true, false, 3>(p); }); return (int)sizeof(wkv7v8x::LdsV8); }   // variant 9 + dealt tile-pair reads + swizzled dS image
+    if (mode == 14) { emu::launch(grid, dim3(768), [&] { wkv7v8x::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, false, false, 3>(p); }); return (int)sizeof(wkv7v8x::LdsV8); }   // variant 8 + the same
+    if (mode == 15) { emu::launch(grid, dim3(768), [&] { wkv7v8x::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, true, false, 4>(p); }); return (int)sizeof(wkv7v8x::LdsV8); }   // variant 9 + S0 by register prefetch in the J waves
+    if (mode == 16) { emu::launch(grid, dim3(768), [&] { wkv7v8x::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, false, false, 4>(p); }); return (int)sizeof(wkv7v8x::LdsV8); }   // variant 8 + the same
     return -1;
 }
 

@@ -265,7 +265,17 @@ template <int IMM> DEVFN void lds_dma16_lean(const void* uniform_base, unsigned 
     VRWKV_LDS_TRACE(7, emu_lds_from_u32(lds_dst_uniform) + IMM + 16 * (emu::flat_tid() & 63))
     memcpy(emu_lds_from_u32(lds_dst_uniform) + IMM + 16 * (emu::flat_tid() & 63), (const char*)uniform_base + lane_byte_off + IMM, 16);   // the immediate moves both ends
 }
+template <int IMM, int CPOL> DEVFN void lds_dma16_lean_cp(const void* uniform_base, unsigned lane_byte_off, unsigned lds_dst_uniform) {
+    lds_dma16_lean<IMM>(uniform_base, lane_byte_off, lds_dst_uniform);
+}
 template <int N_> DEVFN void vmem_wait() {}
+// host versions of the experiment-only primitives of benchmarks/experiments/wkv7_bwd_v8x.h
+#define VRWKV_EMULATED_PRIMS 1
+DEVFN void order_after(bf16x8&, bf16x8&, bf16x8&, bf16x8&) {}
+template <int IMM, int NOPS = 0> DEVFN void global_load16_inplace(f32x4& dst, const void* uniform_base, unsigned lane_byte_off) {
+    memcpy(&dst, (const char*)uniform_base + lane_byte_off + IMM, 16);
+}
+template <int N_> DEVFN void vmem_wait_for(f32x4&, f32x4&, f32x4&, f32x4&) {}
 // empty asm that "redefines" four registers: keeps the compiler from hoisting a derived (e.g. unpacked) form of a loop invariant
 DEVFN void pin_vgpr4(uint32_t&, uint32_t&, uint32_t&, uint32_t&) {}
 DEVFN void vmem_drain() {}

@@ -45,7 +45,7 @@ struct float4 {
 struct float4 { float x, y, z, w; };
 #endif
 struct float2 { float x, y; };
-static inline float4 make_float4(float a, float b, float c, float d) { return float4(a, b, c, d); }
+static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
 static inline float2 make_float2(float a, float b) { return float2{a, b}; }
 static inline uint4 make_uint4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return uint4{a, b, c, d}; }
 static inline uint2 make_uint2(uint32_t a, uint32_t b) { return uint2{a, b}; }

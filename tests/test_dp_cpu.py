@@ -229,19 +229,27 @@ def _worker4(rank, world, port, out_dir):
         fired.append(sorted(n for n, p in m.named_parameters() if n.startswith("proj.") and p.grad is not None and float(p.grad.abs().sum()) > 0))
         eng.step()
     torch.save({"params": {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}, "init": init, "proj_grads_step0": fired[0],
-                "n_buckets": len(eng.buckets)}, os.path.join(out_dir, f"r{rank}.pt"))
+                "n_buckets": len(eng.buckets), "bucket_bounds": [(b.start, b.end, b.piece) for b in eng.buckets], "numel": eng.numel},
+               os.path.join(out_dir, f"r{rank}.pt"))
     eng.close()
     dist.destroy_process_group()
 
 
-def test_world4_gloo_with_a_rank_without_image(tmp_path):
+@pytest.mark.parametrize("W", [4, 8])                      # 8 = the node the bench line is quoted for (BASELINE config 3: DP over 8 GPUs)
+def test_world4_gloo_with_a_rank_without_image(tmp_path, W):
     from visualrwkv_amd.dp import Zero1Engine
-    port = 31500 + os.getpid() % 2000
-    mp.spawn(_worker4, args=(4, port, str(tmp_path)), nprocs=4, join=True)
-    rs = [torch.load(tmp_path / f"r{r}.pt") for r in range(4)]
+    port = 31500 + (os.getpid() + 37 * W) % 2000
+    mp.spawn(_worker4, args=(W, port, str(tmp_path)), nprocs=W, join=True)
+    rs = [torch.load(tmp_path / f"r{r}.pt") for r in range(W)]
     assert rs[0]["n_buckets"] > 2                             # several buckets: the projector's is not the only one
     assert len(rs[0]["proj_grads_step0"]) > 0 and rs[3]["proj_grads_step0"] == []     # rank 3 produced no projector gradient
-    for r in range(1, 4):
+    # bucket geometry at this world size: buckets tile the flat buffer, every bucket is W equal pieces of whole 16-byte groups
+    bounds = rs[0]["bucket_bounds"]
+    assert bounds[0][0] == 0 and bounds[-1][1] == rs[0]["numel"] and all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
+    for st, en, piece in bounds:
+        assert piece * W == en - st and piece % 8 == 0 and st % (8 * W) == 0
+    assert all(r["bucket_bounds"] == bounds for r in rs)
+    for r in range(1, W):
         for n, a in rs[0]["params"].items():
             assert torch.equal(a, rs[r]["params"][n]), n     # replicas stay identical
     # one process: per-record backward (L2Wrap's penalty gradient does not scale with the loss weight, src/model.py:38-46, so the
@@ -251,11 +259,11 @@ def test_world4_gloo_with_a_rank_without_image(tmp_path):
     opt = torch.optim.AdamW(train, lr=_ENG4["lr"], betas=_ENG4["betas"], eps=_ENG4["eps"], weight_decay=0.0)
     for _ in range(2):
         acc = [torch.zeros_like(p) for p in train]
-        for r in range(4):
+        for r in range(W):
             gs = torch.autograd.grad(m.training_step(_rank_batch(r)), train, allow_unused=True)
             for a, g in zip(acc, gs):
                 if g is not None:
-                    a.add_(g, alpha=0.25)
+                    a.add_(g, alpha=1.0 / W)
         gn = float(torch.sqrt(sum((a.double() ** 2).sum() for a in acc)))
         c = min(1.0, _ENG4["grad_clip"] / (gn + 1e-6))
         for p, a in zip(train, acc):

@@ -67,7 +67,7 @@ def test_forward_parity(hip_lib, dev, B, T, H, variant):
     assert rel_rms(sa.cpu(), sar) < 2e-5
 
 
-@pytest.mark.parametrize("variant", [5, 6, 8, 9])       # 9: the default for B x H > 256 (v8 + score pieces a step ahead); 8: wkv7_bwd_v8.h; 6: wkv7_bwd_v6.h (12-wave pipeline; tensors >= 4 GiB); 5: wkv7_bwd_v5.h (8 waves; also the sequence-parallel kernel).  The A/B partners outside the product (7, 10, 11) are tested lane-exactly on the emulator
+@pytest.mark.parametrize("variant", [5, 8, 9])       # 9: the default for B x H > 256 (v8 + score pieces a step ahead); 8: wkv7_bwd_v8.h; 5: wkv7_bwd_v5.h (8 waves; also the sequence-parallel kernel and the kernel of one sample >= 4 GiB).  The A/B partners outside the product (7, 10, 11) are tested lane-exactly on the emulator
 @pytest.mark.parametrize("B,T,H", [(1, 16, 1), (2, 64, 3), (1, 384, 12), (3, 208, 5)])
 def test_backward_parity(hip_lib, dev, B, T, H, variant):
     w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=B * 77 + T + H)
@@ -93,7 +93,7 @@ def test_hip_kernels_against_reference_loop_fixture_n64(hip_lib, dev):
     torch.cuda.synchronize()
     bf16_close(y, g["out"], "y vs reference loop", tol=TOL, max_flip=FLIP_Y)
     assert rel_rms(s[:, :, -1].transpose(-1, -2).double().cpu(), g["final_state"]) < 2e-5
-    for variant in (5, 6, 8, 9):
+    for variant in (5, 8, 9):
         hip_lib.vrwkv_wkv7_set_backward_variant(variant)
         try:
             outs = _capi_backward(hip_lib, *ins, g["dy"].to(dev), s, sa)
@@ -252,6 +252,36 @@ def test_bench_dispatch_against_oracle(hip_lib, dev, B, T, H):
     del s, sa, sr, sar
     for n, o, r in zip(NAMES, outs, ref):
         bf16_close(o, r.float(), f"bench dispatch {n} {B}x{T}x{H}", tol=TOL, max_flip=FLIP_W if n in ("dw", "dz") else FLIP_G)
+
+
+def test_backward_batch_slices(hip_lib, dev):
+    """A launch whose tensors reach the slice limit (4 GiB in production: the default kernel forms 32-bit byte offsets) runs as batch slices of
+    the same kernel on offset pointers, and a single sample above the limit goes to the 64-bit kernel: with the limit lowered to a few hundred
+    KB, (5, 208, 3) runs as slices of 2 + 2 + 1 samples -- bit-identical to the unsliced launch -- and with the limit below one sample the
+    launcher picks wkv7_bwd_v5.h (within the op's tolerance of the oracle)."""
+    B, T, H = 5, 208, 3
+    w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=77)
+    yr, sr, sar = wkv7_c.forward(w, q, k, v, z, a)
+    ref = wkv7_c.backward(w, q, k, v, z, a, dy, sr, sar)
+    d = [x.to(dev) for x in (w, q, k, v, z, a, dy)]
+    y, s, sa = _capi_forward(hip_lib, *d[:6])
+    per_sample = T * H * 64 * 4
+    try:
+        base = _capi_backward(hip_lib, *d, s, sa)
+        assert hip_lib.vrwkv_wkv7_last_variant(1) == 8
+        assert hip_lib.vrwkv_wkv7_set_backward_slice_limit(2 * per_sample + 1) == 0
+        sliced = _capi_backward(hip_lib, *d, s, sa)
+        assert hip_lib.vrwkv_wkv7_last_variant(1) == 8
+        for n, x, r in zip(NAMES, sliced, base):
+            assert torch.equal(x, r), n
+        assert hip_lib.vrwkv_wkv7_set_backward_slice_limit(per_sample // 2) == 0
+        wide = _capi_backward(hip_lib, *d, s, sa)
+        torch.cuda.synchronize()
+        assert hip_lib.vrwkv_wkv7_last_variant(1) == 5
+        for n, x, r in zip(NAMES, wide, ref):
+            assert rel_rms(x.float().cpu(), r.float()) < TOL, n
+    finally:
+        hip_lib.vrwkv_wkv7_set_backward_slice_limit(0)
 
 
 def _capi_forward_state(lib, w, q, k, v, z, a, s0=None, want_final=True, by_products=False):

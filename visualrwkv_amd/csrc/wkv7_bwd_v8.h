@@ -23,58 +23,13 @@
 #include <wkv7_chunked.h>
 #include <wkv7_bwd_rows.h>     // ChunkImg7, RawP, DmaLane, dma_lane, prep7, dscores-style helpers; through it v6 / v5 building blocks
 
-#ifndef VRWKV_V8_OPT
-#define VRWKV_V8_OPT 0
-#endif
-#ifndef VRWKV_V8_ROTATE
-#define VRWKV_V8_ROTATE 1
-#endif
-#ifndef VRWKV_V8_DM_FIRST
-#define VRWKV_V8_DM_FIRST 1
-#endif
-#ifndef VRWKV_V8_PI
-#define VRWKV_V8_PI 0
-#endif
-#ifndef VRWKV_V8_PJ
-#define VRWKV_V8_PJ 0
-#endif
-#ifndef VRWKV_V8_PP
-#define VRWKV_V8_PP 1
-#endif
 #ifndef VRWKV_PROF_WAVE
 #define VRWKV_PROF_WAVE 0       // which wave of each role the PROF instantiation stamps (0 .. 3)
 #endif
-#ifndef VRWKV_V8_SCORES_ON_J
-#define VRWKV_V8_SCORES_ON_J 0
-#endif
-#ifndef VRWKV_V8_CHAINS
-#define VRWKV_V8_CHAINS 0
-#endif
-// issue-cost probe (experiment builds only): N extra scalar / vector / wait instructions per step in the J waves (role 1) or the P waves (role 2)
-#ifndef VRWKV_V8_DUMMY_N
-#define VRWKV_V8_DUMMY_N 0
-#endif
-#ifndef VRWKV_V8_DUMMY_KIND
-#define VRWKV_V8_DUMMY_KIND 0       // 0: s_mov_b32   1: v_mov_b32   2: s_nop 0
-#endif
-#ifndef VRWKV_V8_DUMMY_ROLE
-#define VRWKV_V8_DUMMY_ROLE 1
-#endif
+// The timing / layout knobs of rounds 4 - 6 (role skips, the tail on the J waves, accumulation chains, the issue-cost probe, LDS layouts, S0 by register
+// prefetch, cache policies) live in benchmarks/experiments/wkv7_bwd_v8x.h, a copy of this kernel that only experiment builds compile.
 
 namespace wkv7v8 {
-
-template <int ROLE>
-DEVFN void dummy_issue() {
-#if VRWKV_V8_DUMMY_N > 0
-    if (ROLE != VRWKV_V8_DUMMY_ROLE) return;
-#pragma unroll
-    for (int i = 0; i < VRWKV_V8_DUMMY_N; ++i) {
-        if (VRWKV_V8_DUMMY_KIND == 0) { unsigned t; asm volatile("s_mov_b32 %0, 0" : "=s"(t)); }
-        else if (VRWKV_V8_DUMMY_KIND == 1) { unsigned t; asm volatile("v_mov_b32 %0, 0" : "=v"(t)); }
-        else asm volatile("s_nop 0");
-    }
-#endif
-}
 
 using wkv7::BwdArgs;
 using namespace wkv7c;
@@ -91,13 +46,8 @@ using wkv7v7::dma_lane;
 using wkv7v7::prep7;
 using wkv7v7::dma_chunk;
 using wkv7v7::read_stage;
-using wkv7v7::tail7;
 using wkv7v7::dscores7;
 constexpr int SIMG = N * N;           // elements of a [64][64] image
-// element offset in the [64][64] bf16 dS image: img_off, or (SWZ) with bit 3 of the row folded into the slot swizzle
-template <bool SWZ> DEVFN int dsi_off(int row, int col) {
-    return SWZ ? row * 64 + ((((col >> 3) ^ (row & 7) ^ ((row >> 1) & 4)) << 3) | (col & 7)) : img_off(row, col);
-}
 struct LdsV8 {
     ChunkImg7 b[3];
     uint16_t vdy[4][2][IMG];         // V, dY [t][i] of chunk c in slot c & 3, written by LDS-DMA (swizzled like every image)
@@ -110,10 +60,7 @@ struct LdsV8 {
     float s0[N * N];                 // S0 of the J waves' next chunk (P waves' LDS-DMA, requested when flag 3 says the current one is in registers)
     uint16_t dsi[2][SIMG];           // hi, lo of diag(c_L) dS as the I waves hold it at the start of their step: [i][j] bf16, swizzled like
                                      // every image (I waves -> the J waves' operands one step later; flag 3 hands it back)
-    union {
-        float res[4][IMG];           // J -> P: dZt dQt dAh dKh before the decay factors, fp32 (single: flag 4 hands it back)
-        float x2r[3][IMG];           // JTAIL: log2 c_t [t][j] of chunk c in slot c % 3 (P waves -> the J waves' tail two steps later)
-    };
+    float res[4][IMG];               // J -> P: dZt dQt dAh dKh before the decay factors, fp32 (single: flag 4 hands it back)
     float glast[2][N];               // sum_i dS_L[i][j] S_L[i][j] at the chunk's last token, by chunk parity
     unsigned flag[8];                // 0: M_qa, M_qk, M_zk written (3 per step)  1: dM written (3)  2: T written (1)  3: J operands split (4)
                                      // 4: tail has read `res` (4)  5: P waves hold their staging pieces (4)      (flag 1: four I waves since the score-gradient pieces were re-dealt)
@@ -176,12 +123,7 @@ DEVFN void s0_lean(LdsV8& lds, const float* s_chunk, const LeanLane& ll) {
 }
 
 // ------------------------------------------------------------------------------------------ tail with the prepare's decay factors
-// VRWKV_V8_TAILQ: the queue entry of a chunk also carries c_t and 1 / c_t (8 more registers per entry, three entries) so that the tail,
-// three steps later, does not form them again (8 v_exp_f32 -- quarter rate -- and their DPP moves per lane and step)
-#ifndef VRWKV_V8_TAILQ
-#define VRWKV_V8_TAILQ 0
-#endif
-struct TailQ { uint2 q, k, z, a; float x2[4]; float cc[VRWKV_V8_TAILQ ? 4 : 1], ic[VRWKV_V8_TAILQ ? 4 : 1]; };
+struct TailQ { uint2 q, k, z, a; float x2[4]; };      // what the tail of a chunk needs of its inputs, three steps after the prepare
 struct Prep8 { float x2[4], cc[4], ic[4]; };
 DEVFN Prep8 prep8(ChunkImg7& B, const RawP& raw, int c16, int j0, const LaneAddr& la) {
     float q[4], k[4], z[4], a[4];
@@ -206,7 +148,6 @@ DEVFN Prep8 prep8(ChunkImg7& B, const RawP& raw, int c16, int j0, const LaneAddr
     if (c16 == 15) *reinterpret_cast<float4*>(&B.cl[j0]) = make_float4(o.cc[0], o.cc[1], o.cc[2], o.cc[3]);
     return o;
 }
-template <bool NOSTORE = false>
 DEVFN void tail8(LdsV8& lds, int par, const TailQ& tr, const BwdArgs& p, size_t u, unsigned lane_boff, int c16, int pw, int g, const LaneAddr& la) {
     const float4 zt4 = *reinterpret_cast<const float4*>(&lds.res[0][la.f32]);
     const float4 qt4 = *reinterpret_cast<const float4*>(&lds.res[1][la.f32]);
@@ -223,54 +164,10 @@ DEVFN void tail8(LdsV8& lds, int par, const TailQ& tr, const BwdArgs& p, size_t 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float x2 = tr.x2[e], l2 = x2 - dpp_shr1_fill(x2, 0.f);      // log2 c_t from the queue; log2 w_t = its difference along t
-        const float cc = VRWKV_V8_TAILQ ? tr.cc[VRWKV_V8_TAILQ ? e : 0] : fast_exp2(x2), ic = VRWKV_V8_TAILQ ? tr.ic[VRWKV_V8_TAILQ ? e : 0] : fast_exp2(-x2);
+        const float cc = fast_exp2(x2), ic = fast_exp2(-x2);
         const float cp = dpp_shr1_fill(cc, 1.f);
         dz[e] = dZt[e] * cp; dq[e] = dQt[e] * cc; da[e] = dAh[e] * ic; dk[e] = dKh[e] * ic;
         float gt = dq[e] * q[e] - da[e] * a[e] - dk[e] * k[e] + dpp_shl<1>(dz[e] * z[e]);
-        if (c16 == 15) gt += glv[e];
-        gt += dpp_shl<1>(gt); gt += dpp_shl<2>(gt); gt += dpp_shl<4>(gt); gt += dpp_shl<8>(gt);   // suffix sum over t
-        dw[e] = gt * (l2 * LN2);
-    }
-    auto out = [&](uint16_t* base) { return reinterpret_cast<uint2*>(reinterpret_cast<char*>(base + u) + lane_boff); };   // uniform base + lane offset
-    if (NOSTORE) {          // timing experiment: the results stay "used" (an LDS write nobody reads) but never leave the chip
-        lds.glast[par][16 * pw + 4 * g] = dw[0] + dq[1] + dk[2] + dz[3] + da[0];
-        return;
-    }
-    *out(p.dw) = make_uint2(cvt_pk_bf16(dw[0], dw[1]), cvt_pk_bf16(dw[2], dw[3]));
-    *out(p.dq) = make_uint2(cvt_pk_bf16(dq[0], dq[1]), cvt_pk_bf16(dq[2], dq[3]));
-    *out(p.dk) = make_uint2(cvt_pk_bf16(dk[0], dk[1]), cvt_pk_bf16(dk[2], dk[3]));
-    *out(p.dz) = make_uint2(cvt_pk_bf16(dz[0], dz[1]), cvt_pk_bf16(dz[2], dz[3]));
-    *out(p.da) = make_uint2(cvt_pk_bf16(da[0], da[1]), cvt_pk_bf16(da[2], da[3]));
-}
-
-// The same tail on the J waves (JTAIL): dZt dQt dAh dKh stay in registers (lane = token c16, 4 channels 16w + 4g ..), the operands of
-// the decay-gradient integrand come from the chunk's operand images (hi + lo; this lane's own 8-byte pieces, the layout the P waves wrote),
-// log2 c_t from the ring.  The tail of a chunk runs ONE STEP LATER, between the J waves' own matrix-core phase and their wait for the score
-// gradients (where they stood 0.6-0.9k cycles per step): run right after the chunk's products it lengthened the J waves' dependent chain
-// and the step by 9 % (profiles/r5a_wkv7_ab.jsonl).  The images of a chunk are overwritten in the next step, so the inputs are lifted
-// into registers (JTailIn, 36 registers with the results) at the end of the chunk's own step.
-struct JTailIn { uint2 o[8]; float4 x2; f32x4 dZt, dQt, dAh, dKh; };
-DEVFN void jtail_lift(JTailIn& t, const LdsV8& lds, const ChunkImg7& B, int cj, const f32x4& dZt, const f32x4& dQt, const f32x4& dAh, const f32x4& dKh, const LaneAddr& la) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t.o[i] = ld8(&B.opnd[i][la.own]);
-    t.x2 = *reinterpret_cast<const float4*>(&lds.x2r[cj % 3][la.f32]);
-    t.dZt = dZt; t.dQt = dQt; t.dAh = dAh; t.dKh = dKh;
-}
-DEVFN void jtail_run(const JTailIn& t, const LdsV8& lds, int cj, const BwdArgs& p, size_t u, unsigned lane_boff, int c16, int w, int g) {
-    float zh[4], zl[4], qh[4], ql[4], ah[4], al[4], kh[4], kl[4];
-    unpack4(t.o[0], zh); unpack4(t.o[1], zl); unpack4(t.o[2], qh); unpack4(t.o[3], ql);
-    unpack4(t.o[4], ah); unpack4(t.o[5], al); unpack4(t.o[6], kh); unpack4(t.o[7], kl);
-    const float4 gl4 = *reinterpret_cast<const float4*>(&lds.glast[cj & 1][16 * w + 4 * g]);      // written by this wave a step ago
-    const float x2v[4] = {t.x2.x, t.x2.y, t.x2.z, t.x2.w}, glv[4] = {gl4.x, gl4.y, gl4.z, gl4.w};
-    float dz[4], dq[4], da[4], dk[4], dw[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float x2 = x2v[e], l2 = x2 - dpp_shr1_fill(x2, 0.f);        // log2 w_t = the difference of log2 c_t along t
-        const float cc = fast_exp2(x2), ic = fast_exp2(-x2);
-        const float cp = dpp_shr1_fill(cc, 1.f);
-        dz[e] = t.dZt[e] * cp; dq[e] = t.dQt[e] * cc; da[e] = t.dAh[e] * ic; dk[e] = t.dKh[e] * ic;
-        // dq q - da a - dk k + (dz z)(t+1) with q = Qt / c_t etc.: the decay factors cancel
-        float gt = t.dQt[e] * (qh[e] + ql[e]) - t.dAh[e] * (ah[e] + al[e]) - t.dKh[e] * (kh[e] + kl[e]) + dpp_shl<1>(t.dZt[e] * (zh[e] + zl[e]));
         if (c16 == 15) gt += glv[e];
         gt += dpp_shl<1>(gt); gt += dpp_shl<2>(gt); gt += dpp_shl<4>(gt); gt += dpp_shl<8>(gt);   // suffix sum over t
         dw[e] = gt * (l2 * LN2);
@@ -284,30 +181,13 @@ DEVFN void jtail_run(const JTailIn& t, const LdsV8& lds, int cj, const BwdArgs& 
 }
 
 // ------------------------------------------------------------------------------------------ kernel
-// dbg (PROF): as wkv7_bwd_v6.h.  SKIP (timing experiments only, results are garbage): bit 0 P does nothing, bit 1 I only raises
-// its flags, bit 2 J does nothing.
-// TBF16: the doubling chain of T on the bf16 matrix core with split operands (2 MFMAs + 2 splits per product) or on the f32 one (4 MFMAs of
-// twice the pipe time, no VALU work)
-// PT: priority of P wave 0 while it runs the T chain (back to PP afterwards)
-// AHEAD: the three score pieces (M_qa, M_qk, M_zk) of a chunk are formed by P waves 1-3 at the END of the step in which the chunk's
+// dbg (PROF): as wkv7_bwd_v6.h.
+// AHEAD (variant 9): the three score pieces (M_qa, M_qk, M_zk) of a chunk are formed by P waves 1-3 at the END of the step in which the chunk's
 // images are built -- where those waves stood ~1.9k cycles at the barrier (profiles/r4b_wkv7_phases_waves_v8.jsonl) -- instead of by I
 // waves 1-3 at the start of the next step, where they delayed the i-split's chain by 1.6-1.8k cycles.  The P waves prepare the
 // images BEFORE their tail for that (the queue entry of the prepare is assigned after the tail has consumed the old one).
-// JTAIL (variant 10): the element-wise tail and the five gradient stores run on the J waves, in the step in which they form dZt dQt dAh dKh
-// -- the results never leave their registers -- instead of on the P waves a step later.  One wave issues an instruction every ~5 cycles
-// whatever the other two waves of its SIMD do (profiles/r3_valu_rate.json: 5.5 cycles per VALU instruction at one wave per SIMD, 2.1 at
-// three), so a step lasts as long as its LONGEST wave: per step the P waves issued ~660 (wave 0, with the T chain) / ~545 instructions,
-// the I waves ~445, the J waves ~225 (ISA of the AHEAD instantiation), and the P waves reached the barrier last with 0.2-0.3k cycles of
-// slack (profiles/r4b_wkv7_phases_waves_v8_ahead.jsonl).  The tail is ~165 of them.  On the J waves it needs Zt Qt Ah Kh of the chunk
-// (hi + lo from the operand images: dq q = dQt Qt etc., so the raw inputs are not needed) and log2 c_t (the P waves leave it in a
-// ring of three fp32 images that takes the place of `res`): no three-deep register queue on the P waves, no `res` round trip, no flag 4.
-// OPT (bit mask): 1 = the dS update's transposing reads of tile pairs are dealt so that an instruction touches both halves of its 16-byte slots
-// (rows 4g, 4g+1 of one tile and rows 4g+2, 4g+3 of its neighbour: each of the two reads of a pair returns half of either tile, re-paired in
-// registers for free) -- as two reads of the SAME half they were 2-way bank conflicts by construction (benchmarks/lds_conflicts.py: 128 of the
-// workgroup's 536 conflict cycles per step); 2 = the dS image for the J waves is swizzled with (row & 7) ^ ((row >> 1) & 4), which keeps the
-// I waves' 16-byte writes conflict-free and makes the J waves' transposing reads of rows r and r + 8 land on different banks (64 cycles per step);
-// 64 / 128 (timing experiments only, results are garbage): no tail stores / no S0 requests
-template <bool PROF, int PI = VRWKV_V8_PI, int PJ = VRWKV_V8_PJ, int PP = VRWKV_V8_PP, int SKIP = 0, bool TBF16 = true, int PT = PP, bool AHEAD = false, bool JTAIL = false, int OPT = VRWKV_V8_OPT>
+// Wave priorities: I 0, J 0, P 1 (profiles/r2_wkv7_ab_priority.jsonl, r5_wkv7_jtail_priorities.jsonl).
+template <bool PROF, bool AHEAD = false>
 __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
     LdsV8& lds = *reinterpret_cast<LdsV8*>(dyn_lds());
     const int T = p.T, H = p.H;
@@ -320,14 +200,14 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
     const unsigned bh = blockIdx.x;
     const size_t head_base = ((size_t)(bh / H) * T * H + (bh % H)) * N;
     const float* sbase = p.s + (size_t)bh * nchunk * N * N;
-    const int nsteps = nchunk + (JTAIL ? 2 : 3);       // the last step of the P-tail schedule holds only the tail of chunk 0
+    const int nsteps = nchunk + 3;                      // the last step holds only the tail of chunk 0
     const LaneAddr la = lane_addr(c16, g, w);
     const unsigned out_off = (unsigned)c16 * ts + 16u * w + 4u * g;        // token c16, channels 16w+4g..+3
     WKV_STAMP_DECL
     const unsigned long long rt0_ = PROF ? realtime64_() : 0ull;
 
     if (tid < 8) lds.flag[tid] = 0u;
-    if (role == 2 && !(SKIP & 1)) {                     // rows of the last chunk: staging + its V / dY slot
+    if (role == 2) {                                    // rows of the last chunk: staging + its V / dY slot
         const DmaLane dl = dma_lane(lane, ts);
         dma_chunk(lds, p, head_base + (size_t)(nchunk - 1) * L * ts, nchunk - 1, w, ts, dl);
         vmem_drain();
@@ -336,7 +216,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
 
     if (role == 2) {
         // ================================================================== P: images of chunk cp, T of chunk cp + 1, tail of chunk cp + 3
-        wave_priority<PP>();
+        wave_priority<1>();
         TailQ q0{}, q1{}, q2{};                             // inputs of chunks cp+1, cp+2, cp+3 at the top of a step
         const unsigned lane_boff = out_off * 2u;
         const DmaLane dl = dma_lane(lane, ts);
@@ -353,85 +233,69 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
             constexpr bool SHIFT = decltype(shift_tag)::value;
             const int cp = nchunk - 1 - n, cd = cp + 1, ct = cp + 3;      // images | the I waves' chunk: T now, S0 for the J waves' next step | tail
             WKV_STAMP(4)
-            if (!(SKIP & 1)) {
-                dummy_issue<2>();
-                RawP raw;
-                const bool do_prep = FULL || cp >= 0;
-                if (do_prep) {
-                    raw = read_stage(lds, la);
-                    lds_flag_add(&lds.flag[5]);             // (waits for the reads) ...
-                    n_ps += 4u;
-                    if (w > 0) lds_flag_wait(&lds.flag[5], n_ps);      // ... all four P waves hold their pieces: the staging bytes are free
-                }
-                // waves 1-3 request the rows of the next chunk (6 instructions each); wave 0 has the T chain instead
+            RawP raw;
+            const bool do_prep = FULL || cp >= 0;
+            if (do_prep) {
+                raw = read_stage(lds, la);
+                lds_flag_add(&lds.flag[5]);             // (waits for the reads) ...
+                n_ps += 4u;
+                if (w > 0) lds_flag_wait(&lds.flag[5], n_ps);      // ... all four P waves hold their pieces: the staging bytes are free
+            }
+            // waves 1-3 request the rows of the next chunk (6 instructions each); wave 0 has the T chain instead
+            if (FULL) {
+                const unsigned cb16 = (unsigned)((head_base + (size_t)(cp - 1) * L * ts) * 2u);
+                if (w == 1) rows_lean<0>(lds, p, cp - 1, cb16, ll); else if (w == 2) rows_lean<1>(lds, p, cp - 1, cb16, ll);
+                else if (w == 3) rows_lean<2>(lds, p, cp - 1, cb16, ll);
+            } else if (w > 0 && cp >= 1) dma_chunk<LdsV8, 3>(lds, p, head_base + (size_t)(cp - 1) * L * ts, cp - 1, w - 1, ts, dl);
+            Prep8 dd{};
+            if (AHEAD && w > 0 && do_prep) { dd = prep8(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la); lds_flag_add(&lds.flag[6]); }
+            // T = (I - M_za)^-1 of the I waves' chunk, from the images this role built a step ago: the doubling chain is 28
+            // dependent MFMA / split stages and nobody needs T before the I waves have formed dSA
+            if (w == 0 && (FULL || (cd >= 0 && cd <= nchunk - 1))) {
+                wkv7v6::scores6<true, LdsV8, ChunkImg7, true>(lds, lds.b[cd % 3], 0, c16, g, la);
+                lds_flag_add(&lds.flag[2]);
+            }
+            if (AHEAD && w == 0 && do_prep) { dd = prep8(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la); lds_flag_add(&lds.flag[6]); }
+            // the J waves have lifted S0 and their dS operands into registers (and split them: VALU only, like the tail, which
+            // therefore runs beside their matrix-core phase); J is active in steps 2 .. nchunk + 1 and counts 4 per step
+            if (FULL || (n >= 2 && n <= nchunk + 1)) lds_flag_wait(&lds.flag[3], 4u * (unsigned)(n - 1));
+            // S0 of chunk cd = s[cd-1] for the j-split of the next step, into the image the J waves have just left
+            {
+                const int k0 = w == 1 ? 0 : w == 2 ? 5 : 10, k1 = w == 0 ? 0 : w == 1 ? 5 : w == 2 ? 10 : 16;      // waves 1-3: 5 5 6 KB
                 if (FULL) {
-                    const unsigned cb16 = (unsigned)((head_base + (size_t)(cp - 1) * L * ts) * 2u);
-                    if (w == 1) rows_lean<0>(lds, p, cp - 1, cb16, ll); else if (w == 2) rows_lean<1>(lds, p, cp - 1, cb16, ll);
-                    else if (w == 3) rows_lean<2>(lds, p, cp - 1, cb16, ll);
-                } else if (w > 0 && cp >= 1) dma_chunk<LdsV8, 3>(lds, p, head_base + (size_t)(cp - 1) * L * ts, cp - 1, w - 1, ts, dl);
-                Prep8 dd{};
-                if (AHEAD && w > 0 && do_prep) { dd = prep8(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la); lds_flag_add(&lds.flag[6]); }
-                // T = (I - M_za)^-1 of the I waves' chunk, from the images this role built a step ago: the doubling chain is 28
-                // dependent MFMA / split stages and nobody needs T before the I waves have formed dSA
-                if (w == 0 && (FULL || (cd >= 0 && cd <= nchunk - 1))) {
-                    if (PT != PP) wave_priority<PT>();
-                    if (!(SKIP & 8)) wkv7v6::scores6<TBF16, LdsV8, ChunkImg7, true>(lds, lds.b[cd % 3], 0, c16, g, la);      // SKIP bit 3 (timing experiment): no T chain
-                    lds_flag_add(&lds.flag[2]);
-                    if (PT != PP) wave_priority<PP>();
-                }
-                if (AHEAD && w == 0 && do_prep) { dd = prep8(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la); lds_flag_add(&lds.flag[6]); }
-                // the J waves have lifted S0 and their dS operands into registers (and split them: VALU only, like the tail, which
-                // therefore runs beside their matrix-core phase); J is active in steps 2 .. nchunk + 1 and counts 4 per step
-                if (!(SKIP & 4) && (FULL || (n >= 2 && n <= nchunk + 1))) lds_flag_wait(&lds.flag[3], 4u * (unsigned)(n - 1));
-                // S0 of chunk cd = s[cd-1] for the j-split of the next step, into the image the J waves have just left
-                {
-                    const int k0 = w == 1 ? 0 : w == 2 ? 5 : 10, k1 = w == 0 ? 0 : w == 1 ? 5 : w == 2 ? 10 : 16;      // waves 1-3: 5 5 6 KB
-                    if (OPT & 128) {
-                    } else if (FULL) {
-                        const float* sc = sbase + (size_t)(cd - 1) * N * N;
-                        if (w == 1) s0_lean<0>(lds, sc, ll); else if (w == 2) s0_lean<1>(lds, sc, ll); else if (w == 3) s0_lean<2>(lds, sc, ll);
-                    } else if (cd >= 0 && cd <= nchunk - 1) dma_state(lds.s0, cd > 0 ? sbase + (size_t)(cd - 1) * N * N : nullptr, k0, k1, lane);
-                }
-                if (!JTAIL && (FULL || (ct >= 0 && ct <= nchunk - 1))) tail8<(OPT & 64) != 0>(lds, ct & 1, qt, p, head_base + (size_t)ct * L * ts, lane_boff, c16, w, g, la);
-                WKV_STAMP(0)
-                if (SHIFT && !JTAIL) { q2 = q1; q1 = q0; }
-                TailQ& qn = SHIFT ? q0 : qt;
-                if (do_prep && JTAIL) {
-                    if (!AHEAD) dd = prep8(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la);
-                    *reinterpret_cast<float4*>(&lds.x2r[cp % 3][la.f32]) = make_float4(dd.x2[0], dd.x2[1], dd.x2[2], dd.x2[3]);
-                }
-                if (do_prep && !JTAIL) {
-                    if (!AHEAD) dd = prep8(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la);
-                    qn.q = raw.q; qn.k = raw.k; qn.z = raw.z; qn.a = raw.a;
-                    qn.x2[0] = dd.x2[0]; qn.x2[1] = dd.x2[1]; qn.x2[2] = dd.x2[2]; qn.x2[3] = dd.x2[3];
-                    if (VRWKV_V8_TAILQ) {
-#pragma unroll
-                        for (int e = 0; e < (VRWKV_V8_TAILQ ? 4 : 1); ++e) { qn.cc[e] = dd.cc[e]; qn.ic[e] = dd.ic[e]; }
-                    }
-                }
-                if (AHEAD && w > 0 && do_prep) {
-                    // scores of chunk cp for the I waves' next step: all four P waves' images are written (flag 6), and the I waves are
-                    // past the last use of the previous scores (flag 0: four per step in which they are active, steps 1 ..)
-                    lds_flag_wait(&lds.flag[6], 4u * (unsigned)(n + 1));
-                    if (n >= 1) lds_flag_wait(&lds.flag[0], 4u * (unsigned)n);
-                    wkv7v6::scores6<true>(lds, lds.b[cp % 3], w, c16, g, la);
-                }
-                WKV_STAMP(1)
-                if (FULL && !JTAIL && !(OPT & 64)) vmem_wait<5>(); else vmem_drain();      // JTAIL: this role issues requests only
-            } else if (w == 0 && cd >= 0 && cd <= nchunk - 1) lds_flag_add(&lds.flag[2]);
+                    const float* sc = sbase + (size_t)(cd - 1) * N * N;
+                    if (w == 1) s0_lean<0>(lds, sc, ll); else if (w == 2) s0_lean<1>(lds, sc, ll); else if (w == 3) s0_lean<2>(lds, sc, ll);
+                } else if (cd >= 0 && cd <= nchunk - 1) dma_state(lds.s0, cd > 0 ? sbase + (size_t)(cd - 1) * N * N : nullptr, k0, k1, lane);
+            }
+            if (FULL || (ct >= 0 && ct <= nchunk - 1)) tail8(lds, ct & 1, qt, p, head_base + (size_t)ct * L * ts, lane_boff, c16, w, g, la);
+            WKV_STAMP(0)
+            if (SHIFT) { q2 = q1; q1 = q0; }
+            TailQ& qn = SHIFT ? q0 : qt;
+            if (do_prep) {
+                if (!AHEAD) dd = prep8(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la);
+                qn.q = raw.q; qn.k = raw.k; qn.z = raw.z; qn.a = raw.a;
+                qn.x2[0] = dd.x2[0]; qn.x2[1] = dd.x2[1]; qn.x2[2] = dd.x2[2]; qn.x2[3] = dd.x2[3];
+            }
+            if (AHEAD && w > 0 && do_prep) {
+                // scores of chunk cp for the I waves' next step: all four P waves' images are written (flag 6), and the I waves are
+                // past the last use of the previous scores (flag 0: four per step in which they are active, steps 1 ..)
+                lds_flag_wait(&lds.flag[6], 4u * (unsigned)(n + 1));
+                if (n >= 1) lds_flag_wait(&lds.flag[0], 4u * (unsigned)n);
+                wkv7v6::scores6<true>(lds, lds.b[cp % 3], w, c16, g, la);
+            }
+            WKV_STAMP(1)
+            if (FULL) vmem_wait<5>(); else vmem_drain();
             WKV_STAMP(2)
             block_sync_lds();
             WKV_STAMP(3)
         };
         int n = 0;
         for (; n < 3 && n < nsteps; ++n) pstep(n, BoolTag<false>{}, q2, BoolTag<true>{});
-#if VRWKV_V8_ROTATE
-        for (; !JTAIL && n + 2 < nchunk - 1; n += 3) {  // three steps: the entries rotate through the names and are back in place (JTAIL has no queue)
+        for (; n + 2 < nchunk - 1; n += 3) {            // three steps: the entries rotate through the names and are back in place
             pstep(n, BoolTag<true>{}, q2, BoolTag<false>{});
             pstep(n + 1, BoolTag<true>{}, q1, BoolTag<false>{});
             pstep(n + 2, BoolTag<true>{}, q0, BoolTag<false>{});
         }
-#endif
         for (; n < nchunk - 1; ++n) pstep(n, BoolTag<true>{}, q2, BoolTag<true>{});
         for (; n < nsteps; ++n) pstep(n, BoolTag<false>{}, q2, BoolTag<true>{});
         WKV_STAMP_FLUSH(512 + 64 * VRWKV_PROF_WAVE, 10, 5)
@@ -440,16 +304,13 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
 
     if (role == 0) {
         // ================================================================== I: chunk ci = nchunk - n  (steps 1 .. nchunk)
-        wave_priority<PI>();
+        wave_priority<0>();
         f32x4 dS1[4];                                       // dS1[jb][r] = dS[i = 16w+c16][j = tix(jb, 4g+r)]: the only copy of dL/dS
 #pragma unroll
         for (int x = 0; x < 4; ++x) dS1[x] = zero4();
         unsigned n_sc = 0, n_t = 0;
-        const int img_row = dsi_off<(OPT & 2) != 0>(16 * w + c16, 8 * g);   // this lane's 16-byte piece of the dS image, k block 0 (+ 32 columns: block 1)
-        const int img_row1 = dsi_off<(OPT & 2) != 0>(16 * w + c16, 32 + 8 * g);
-        // OPT & 1: transposing reads of a tile pair, dealt over both halves of the 16-byte slots (see the template comment)
-        const int hb4 = 4 * ((c16 >> 3) & 1);
-        const int tra[2] = {la.tri[0] + hb4, la.tri[1] + hb4}, trb[2] = {la.tri[0] + 4 - hb4, la.tri[1] + 4 - hb4};
+        const int img_row = img_off(16 * w + c16, 8 * g);   // this lane's 16-byte piece of the dS image, k block 0 (+ 32 columns: block 1)
+        const int img_row1 = img_off(16 * w + c16, 32 + 8 * g);
         for (int n = 0; n < nsteps; ++n) {
             const int ci = nchunk - n, cj = ci + 1;         // this role's chunk | the J waves' chunk of this step
             WKV_STAMP(4)
@@ -458,26 +319,22 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
             // Score gradients of the J waves' chunk FIRST (their dR is one step old): the J waves need them in the middle of THIS step
             // (their dM products), the scores below are for this role's own i-split.  With the scores first the J waves stood
             // 1.2k cycles per step at flag 1 (profiles/r4_wkv7_phases_b16.json: J_dMwait) and carried the step's critical path.
-            auto score_grads = [&]() {
-                if (cj >= 0 && cj <= nchunk - 1) {
-                    const ChunkImg7& Bj = lds.b[cj % 3];
-                    const uint16_t *vi = lds.vdy[cj & 3][0], *dyi = lds.vdy[cj & 3][1], *drh = lds.dr[cj & 1][0], *drl = lds.dr[cj & 1][1];
-                    // wave 0: dM_za (6 MFMAs; it has no score piece and would stand at flag 0 meanwhile)  1: dM_qk (2)  2: dM_qa (4)  3: dM_zk (4)
-                    if (!(SKIP & 2)) dscores7(lds, Bj.sa[0], Bj.sa[1], vi, dyi, drh, drl, w == 0 ? 0 : w == 1 ? 3 : w == 2 ? 2 : 1, c16, g, la);
-                    lds_flag_add(&lds.flag[1]);
-                }
-            };
-            if (VRWKV_V8_DM_FIRST) score_grads();
+            if (cj >= 0 && cj <= nchunk - 1) {
+                const ChunkImg7& Bj = lds.b[cj % 3];
+                const uint16_t *vi = lds.vdy[cj & 3][0], *dyi = lds.vdy[cj & 3][1], *drh = lds.dr[cj & 1][0], *drl = lds.dr[cj & 1][1];
+                // wave 0: dM_za (6 MFMAs; it has no score piece and would stand at flag 0 meanwhile)  1: dM_qk (2)  2: dM_qa (4)  3: dM_zk (4)
+                dscores7(lds, Bj.sa[0], Bj.sa[1], vi, dyi, drh, drl, w == 0 ? 0 : w == 1 ? 3 : w == 2 ? 2 : 1, c16, g, la);
+                lds_flag_add(&lds.flag[1]);
+            }
             if (ci >= 0 && ci <= nchunk - 1) {
-                if (w > 0 && !VRWKV_V8_SCORES_ON_J && !AHEAD) {
-                    if (!(SKIP & 2)) wkv7v6::scores6<true>(lds, lds.b[ci % 3], w, c16, g, la);
+                if (w > 0 && !AHEAD) {
+                    wkv7v6::scores6<true>(lds, lds.b[ci % 3], w, c16, g, la);
                     lds_flag_add(&lds.flag[0]);
                 }
                 n_sc += 3; n_t += 1;
             }
-            if (!VRWKV_V8_DM_FIRST) score_grads();
             WKV_STAMP(0)
-            if (!(SKIP & 2) && ci >= 0 && ci <= nchunk - 1) {
+            if (ci >= 0 && ci <= nchunk - 1) {
                 const ChunkImg7& B = lds.b[ci % 3];
                 const uint16_t* dyi = lds.vdy[ci & 3][1];
                 const size_t cbase = head_base + (size_t)ci * L * ts;
@@ -491,51 +348,24 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                 }
                 bf16x8 sh[2], sl[2];
                 tiles_op(dSc, sh, sl);
-                // VRWKV_V8_CHAINS: 0 = one accumulation chain per product (7 / 9 dependent MFMAs), 1 = two chains (k block 0 | k block 1), 2 = two
-                // chains with the products that need no other role's results (dS with this chunk's Ah / Kh images) issued before the
-                // waits for the score pieces and T
-                f32x4 c0 = zero4(), c1 = zero4(), v0 = zero4(), v1 = zero4();
-                auto own_products = [&]() {
-                    const bf16x8 ah0 = ld16(&B.opnd[4][la.row[0]]), ah1 = ld16(&B.opnd[4][la.row[1]]);
-                    const bf16x8 kh0 = ld16(&B.opnd[6][la.row[0]]), kh1 = ld16(&B.opnd[6][la.row[1]]);
-                    c0 = mfma32(ah0, sh[0], c0);
-                    c1 = mfma32(ah1, sh[1], c1);
-                    v0 = mfma32(sh[0], kh0, v0);
-                    v1 = mfma32(sh[1], kh1, v1);
-                    c0 = mfma32(ah0, sl[0], c0);
-                    c1 = mfma32(ah1, sl[1], c1);
-                    v0 = mfma32(sl[0], kh0, v0);
-                    v1 = mfma32(sl[1], kh1, v1);
-                    c0 = mfma32(ld16(&B.opnd[5][la.row[0]]), sh[0], c0);
-                    c1 = mfma32(ld16(&B.opnd[5][la.row[1]]), sh[1], c1);
-                    v0 = mfma32(sh[0], ld16(&B.opnd[7][la.row[0]]), v0);
-                    v1 = mfma32(sh[1], ld16(&B.opnd[7][la.row[1]]), v1);
-                };
-                if (VRWKV_V8_CHAINS == 2) own_products();
                 // the same operands, one step later, for the J waves: lane (i, g) holds columns j = 32 kb + 8g .. +7 of row i.  The J
                 // waves took their operands of the previous image at the top of this step (flag 3; J is active in steps 2 .. nchunk+1)
-                if (!(SKIP & 4) && n >= 2 && n <= nchunk + 1) lds_flag_wait(&lds.flag[3], 4u * (unsigned)(n - 1));
+                if (n >= 2 && n <= nchunk + 1) lds_flag_wait(&lds.flag[3], 4u * (unsigned)(n - 1));
                 *reinterpret_cast<bf16x8*>(&lds.dsi[0][img_row]) = sh[0]; *reinterpret_cast<bf16x8*>(&lds.dsi[0][img_row1]) = sh[1];
                 *reinterpret_cast<bf16x8*>(&lds.dsi[1][img_row]) = sl[0]; *reinterpret_cast<bf16x8*>(&lds.dsi[1][img_row1]) = sl[1];
                 if (!AHEAD) lds_flag_wait(&lds.flag[0], n_sc);
                 WKV_STAMP(1)
                 const uint2 dyv = lds_read_tr16(&dyi[la.trc]);                   // dY[4g+e][i]
                 const bf16x8 dyd = mk8(dyv, dyv);
-                // dSA[t][i] = sum_s M_qa[s][t] dY[s][i] + sum_j Ah[t][j] c_L[j] dS[i][j]
-                f32x4 dSA;
-                if (VRWKV_V8_CHAINS == 0) {
-                    dSA = mfma32(ld16(&lds.sc[0][la.hl]), dyd, zero4());
+                // dSA[t][i] = sum_s M_qa[s][t] dY[s][i] + sum_j Ah[t][j] c_L[j] dS[i][j]      (one accumulation chain per product: two chains, and
+                // chunk-local products issued before the waits, measured slower -- profiles/r4_wkv7_ab.jsonl)
+                f32x4 dSA = mfma32(ld16(&lds.sc[0][la.hl]), dyd, zero4());
 #pragma unroll
-                    for (int kb = 0; kb < 2; ++kb) {
-                        const bf16x8 ah = ld16(&B.opnd[4][la.row[kb]]);
-                        dSA = mfma32(ah, sh[kb], dSA);
-                        dSA = mfma32(ah, sl[kb], dSA);
-                        dSA = mfma32(ld16(&B.opnd[5][la.row[kb]]), sh[kb], dSA);
-                    }
-                } else {
-                    if (VRWKV_V8_CHAINS == 1) own_products();
-                    c0 = mfma32(ld16(&lds.sc[0][la.hl]), dyd, c0);
-                    dSA = c0 + c1;
+                for (int kb = 0; kb < 2; ++kb) {
+                    const bf16x8 ah = ld16(&B.opnd[4][la.row[kb]]);
+                    dSA = mfma32(ah, sh[kb], dSA);
+                    dSA = mfma32(ah, sl[kb], dSA);
+                    dSA = mfma32(ld16(&B.opnd[5][la.row[kb]]), sh[kb], dSA);
                 }
                 uint2 xh, xl, rh, rl;
                 split4(dSA, xh, xl);
@@ -558,62 +388,32 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                 // dV^T[i][t] = sum_j c_L[j] dS[i][j] Kh[t][j] + sum_s dY[s][i] M_qk[s][t] + sum_s dR[s][i] M_zk[s][t]
                 {
                     const bf16x8 rhl = mk8(rh, rl);
-                    f32x4 dV;
-                    if (VRWKV_V8_CHAINS == 0) {
-                        dV = mfma32(dyd, ld16(&lds.sc[1][la.hl]), zero4());
+                    f32x4 dV = mfma32(dyd, ld16(&lds.sc[1][la.hl]), zero4());
 #pragma unroll
-                        for (int kb = 0; kb < 2; ++kb) {
-                            const bf16x8 kh = ld16(&B.opnd[6][la.row[kb]]);
-                            dV = mfma32(sh[kb], kh, dV);
-                            dV = mfma32(sl[kb], kh, dV);
-                            dV = mfma32(sh[kb], ld16(&B.opnd[7][la.row[kb]]), dV);
-                        }
-                        dV = mfma32(rhl, ld16(&lds.dz[0][la.row[0]]), dV);                 // [M_zk_h M_zk_h]
-                        dV = mfma32(rhl, ld16(&lds.dz[0][la.row[1]]), dV);                 // [M_zk_l 0]
-                    } else {
-                        v0 = mfma32(dyd, ld16(&lds.sc[1][la.hl]), v0);
-                        v1 = mfma32(rhl, ld16(&lds.dz[0][la.row[0]]), v1);
-                        v0 = mfma32(rhl, ld16(&lds.dz[0][la.row[1]]), v0);
-                        dV = v0 + v1;
+                    for (int kb = 0; kb < 2; ++kb) {
+                        const bf16x8 kh = ld16(&B.opnd[6][la.row[kb]]);
+                        dV = mfma32(sh[kb], kh, dV);
+                        dV = mfma32(sl[kb], kh, dV);
+                        dV = mfma32(sh[kb], ld16(&B.opnd[7][la.row[kb]]), dV);
                     }
+                    dV = mfma32(rhl, ld16(&lds.dz[0][la.row[0]]), dV);                 // [M_zk_h M_zk_h]
+                    dV = mfma32(rhl, ld16(&lds.dz[0][la.row[1]]), dV);                 // [M_zk_l 0]
                     *reinterpret_cast<uint2*>(p.dv + cbase + out_off) = make_uint2(cvt_pk_bf16(dV[0], dV[1]), cvt_pk_bf16(dV[2], dV[3]));
                 }
                 if (AHEAD) lds_flag_add(&lds.flag[0]);            // (waits for the reads) the scores of this chunk are consumed
                 WKV_STAMP(6)
                 // dS^T <- diag(c_L) dS^T + [Qt^T | Zt^T] [dY ; dR]
                 const bf16x8 y1 = mk8(dyv, rh), y2 = mk8(0u, 0u, rl.x, rl.y);
-                if (OPT & 1) {
 #pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {
-                        // read A: rows 4g, 4g+1 of the even tile | rows 4g+2, 4g+3 of the odd one; read B: the complement
-                        const uint2 qha = lds_read_tr16(&B.opnd[2][tra[pr]]), qhb = lds_read_tr16(&B.opnd[2][trb[pr]]);
-                        const uint2 zha = lds_read_tr16(&B.opnd[0][tra[pr]]), zhb = lds_read_tr16(&B.opnd[0][trb[pr]]);
-                        const uint2 qla = lds_read_tr16(&B.opnd[3][tra[pr]]), qlb = lds_read_tr16(&B.opnd[3][trb[pr]]);
-                        const uint2 zla = lds_read_tr16(&B.opnd[1][tra[pr]]), zlb = lds_read_tr16(&B.opnd[1][trb[pr]]);
-#pragma unroll
-                        for (int od = 0; od < 2; ++od) {
-                            const int jb = 2 * pr + od;
-                            f32x4 acc = dSc[jb];
-                            const bf16x8 xh8 = od ? mk8(qhb.x, qha.y, zhb.x, zha.y) : mk8(qha.x, qhb.y, zha.x, zhb.y);
-                            const bf16x8 xl8 = od ? mk8(qlb.x, qla.y, zlb.x, zla.y) : mk8(qla.x, qlb.y, zla.x, zlb.y);
-                            acc = mfma32(xh8, y1, acc);
-                            acc = mfma32(xl8, y1, acc);
-                            acc = mfma32(xh8, y2, acc);
-                            dS1[jb] = acc;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int jb = 0; jb < 4; ++jb) {
-                        f32x4 acc = dSc[jb];
-                        const int o = la.tri[jb >> 1] + 4 * (jb & 1);
-                        const bf16x8 xh8 = mk8(lds_read_tr16(&B.opnd[2][o]), lds_read_tr16(&B.opnd[0][o]));
-                        const bf16x8 xl8 = mk8(lds_read_tr16(&B.opnd[3][o]), lds_read_tr16(&B.opnd[1][o]));
-                        acc = mfma32(xh8, y1, acc);
-                        acc = mfma32(xl8, y1, acc);
-                        acc = mfma32(xh8, y2, acc);
-                        dS1[jb] = acc;
-                    }
+                for (int jb = 0; jb < 4; ++jb) {
+                    f32x4 acc = dSc[jb];
+                    const int o = la.tri[jb >> 1] + 4 * (jb & 1);
+                    const bf16x8 xh8 = mk8(lds_read_tr16(&B.opnd[2][o]), lds_read_tr16(&B.opnd[0][o]));
+                    const bf16x8 xl8 = mk8(lds_read_tr16(&B.opnd[3][o]), lds_read_tr16(&B.opnd[1][o]));
+                    acc = mfma32(xh8, y1, acc);
+                    acc = mfma32(xl8, y1, acc);
+                    acc = mfma32(xh8, y2, acc);
+                    dS1[jb] = acc;
                 }
             }
             WKV_STAMP(2)
@@ -626,26 +426,20 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
     }
 
     // ====================================================================== J: chunk cj = nchunk + 1 - n  (steps 2 .. nchunk + 1)
-    wave_priority<PJ>();
+    wave_priority<0>();
     const int j = 16 * w + c16;                         // key column of the j-split tiles
     // transposing reads of the dS image: operand rows j = 16w + c16, k = i = 32 kb + 8g + e: rows 32 kb + 8g + 4h + (c16 >> 2)
     int tro[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) tro[kb][h] = dsi_off<(OPT & 2) != 0>(32 * kb + 8 * g + 4 * h + (c16 >> 2), 16 * w + 4 * (c16 & 3));
+        for (int h = 0; h < 2; ++h) tro[kb][h] = img_off(32 * kb + 8 * g + 4 * h + (c16 >> 2), 16 * w + 4 * (c16 & 3));
     bf16x8 s0h_p[2] = {mk8(0u, 0u, 0u, 0u), mk8(0u, 0u, 0u, 0u)}, s0l_p[2] = {mk8(0u, 0u, 0u, 0u), mk8(0u, 0u, 0u, 0u)};   // S0 operands of the previous step = S_L of this one
     unsigned n_dm = 0;
-    JTailIn jt{};                                       // JTAIL: results and tail inputs of the chunk of the previous step
     for (int n = 0; n < nsteps; ++n) {
         const int cj = nchunk + 1 - n;
         WKV_STAMP(4)
-        if (VRWKV_V8_SCORES_ON_J && w < 3 && cj - 1 >= 0 && cj - 1 <= nchunk - 1) {      // experiment: the I waves' three score pieces on J waves 0-2
-            wkv7v6::scores6<true>(lds, lds.b[(cj - 1) % 3], w + 1, c16, g, la);
-            lds_flag_add(&lds.flag[0]);
-        }
-        if (!(SKIP & 4) && cj >= 0 && cj <= nchunk - 1) {
-            dummy_issue<1>();
+        if (cj >= 0 && cj <= nchunk - 1) {
             const ChunkImg7& B = lds.b[cj % 3];
             const uint16_t* drh = lds.dr[cj & 1][0];
             const uint16_t* drl = lds.dr[cj & 1][1];
@@ -724,8 +518,6 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                 WKV_STAMP(6)
             }
             WKV_STAMP(0)
-            // the tail of the previous step's chunk: VALU + stores beside this chunk's matrix-core phase and the wait for its score gradients
-            if (JTAIL && cj + 1 <= nchunk - 1) jtail_run(jt, lds, cj + 1, p, head_base + (size_t)(cj + 1) * L * ts, out_off * 2u, c16, w, g);
             WKV_STAMP(7)
             // ---------------------------------------------------------------- dM products
             const bf16x8 qzh = mk8(lds_read_tr16(&B.opnd[2][la.trc]), lds_read_tr16(&B.opnd[0][la.trc]));      // [Qt^T | Zt^T]
@@ -761,21 +553,16 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
             }
             // results: lane = token c16, registers = channels 16w + 4g + e -> the fp32 image of the P waves' tail, once the tail of
             // the chunk before (this step's, steps 3 ..) has read it: 4 P waves per tail
-            if (JTAIL) {
-                jtail_lift(jt, lds, B, cj, dZt, dQt, dAh, dKh, la);
-            } else {
-                if (!(SKIP & 1) && n >= 3) lds_flag_wait(&lds.flag[4], 4u * (unsigned)(n - 2));
-                *reinterpret_cast<float4*>(&lds.res[0][la.f32]) = make_float4(dZt[0], dZt[1], dZt[2], dZt[3]);
-                *reinterpret_cast<float4*>(&lds.res[1][la.f32]) = make_float4(dQt[0], dQt[1], dQt[2], dQt[3]);
-                *reinterpret_cast<float4*>(&lds.res[2][la.f32]) = make_float4(dAh[0], dAh[1], dAh[2], dAh[3]);
-                *reinterpret_cast<float4*>(&lds.res[3][la.f32]) = make_float4(dKh[0], dKh[1], dKh[2], dKh[3]);
-            }
+            if (n >= 3) lds_flag_wait(&lds.flag[4], 4u * (unsigned)(n - 2));
+            *reinterpret_cast<float4*>(&lds.res[0][la.f32]) = make_float4(dZt[0], dZt[1], dZt[2], dZt[3]);
+            *reinterpret_cast<float4*>(&lds.res[1][la.f32]) = make_float4(dQt[0], dQt[1], dQt[2], dQt[3]);
+            *reinterpret_cast<float4*>(&lds.res[2][la.f32]) = make_float4(dAh[0], dAh[1], dAh[2], dAh[3]);
+            *reinterpret_cast<float4*>(&lds.res[3][la.f32]) = make_float4(dKh[0], dKh[1], dKh[2], dKh[3]);
         }
         WKV_STAMP(2)
         block_sync_lds();
         WKV_STAMP(3)
     }
-    if (JTAIL && !(SKIP & 4)) jtail_run(jt, lds, 0, p, head_base, out_off * 2u, c16, w, g);          // the tail of chunk 0
     WKV_STAMP_FLUSH(256 + 64 * VRWKV_PROF_WAVE, 5, 5)
     if (PROF && blockIdx.x == 0 && tid == 256 + 64 * VRWKV_PROF_WAVE) { p.dbg[16] = tacc_[5]; p.dbg[17] = tacc_[6]; p.dbg[20] = tacc_[7]; }   // j-split: operand reads + split | outputs
 }

@@ -7,7 +7,7 @@
 #include <wkv7_fwd_v3.h>
 #include <wkv7_fwd_v4.h>
 #include <wkv7_bwd_v5.h>
-#include <wkv7_bwd_v6.h>
+#include <wkv7_bwd_v6.h>     // shared building blocks of the backward kernels
 #include <wkv7_bwd_v8.h>
 #ifdef VRWKV_V6_EXPERIMENTS
 #include <wkv7_experiments.h>
@@ -28,9 +28,13 @@ std::atomic<int> g_last_fwd{0}, g_last_bwd{0};
 // 0.358 -> 0.331 -> 0.324 ms, B=16 0.647 -> 0.637 -> 0.627 ms.  Variant 1 = the round-2 instantiation.
 #define VRWKV_FWD_DEFAULT wkv7c::fwd_kernel_v3<false, false, 1, 1, false, true, true>
 #define VRWKV_FWD_ISPLIT wkv7c::fwd_kernel_v3<false, false, 1, 1, false, true, true, true>      // two workgroups per head
-// backward: 5 = wkv7_bwd_v5.h (8 waves; also the sequence-parallel kernel), 6 = wkv7_bwd_v6.h (12-wave pipeline, 8-byte register loads: tensors of
-// 4 GiB and more), 8 = wkv7_bwd_v8.h (one dS copy, T chain on P wave 0, full-row LDS-DMA), 9 = 8 with the score pieces a step ahead on the P waves
+// backward: 5 = wkv7_bwd_v5.h (8 waves; also the sequence-parallel kernel), 8 = wkv7_bwd_v8.h (one dS copy, T chain on P wave 0, full-row LDS-DMA),
+// 9 = 8 with the score pieces a step ahead on the P waves.  (6 = the round-3 kernel, experiment builds only: benchmarks/experiments/wkv7_bwd_v6_kernel.h)
 constexpr int BWD_DEFAULT = 9;
+// wkv7_bwd_v8.h forms 32-bit byte offsets inside a tensor (the largest is the fp32 `sa`): a launch whose tensors reach this many bytes is cut into
+// batch slices below it (every tensor of the op is batch-major, so a slice is the same launch on offset pointers); a single sample that large goes
+// to wkv7_bwd_v5.h, which addresses with 64 bits.  vrwkv_wkv7_set_backward_slice_limit lowers it for tests.
+std::atomic<unsigned long long> g_slice_limit{1ull << 32};
 
 // The kernel a forward launch of `heads` = B x H workgroups uses under override `forced` (-1: none): 7 = wkv7_fwd_v4.h (full-row memory traffic)
 // when the heads alone give every CU a workgroup pair's worth of work, 6 = wkv7_fwd_v3.h with two workgroups per head below that, else the forced
@@ -67,12 +71,17 @@ int vrwkv_wkv7_set_forward_variant(int variant) {
 }
 
 int vrwkv_wkv7_set_backward_variant(int variant) {
-    bool ok = variant == -1 || variant == 5 || variant == 6 || variant == 8 || variant == 9;      // see include/visualrwkv_hip.h
+    bool ok = variant == -1 || variant == 5 || variant == 8 || variant == 9;      // see include/visualrwkv_hip.h
 #ifdef VRWKV_V6_EXPERIMENTS
     ok = ok || wkv7exp::is_experiment(variant);
 #endif
     if (!ok) return VRWKV_EINVAL;
     g_bwd_variant = variant;
+    return VRWKV_OK;
+}
+
+int vrwkv_wkv7_set_backward_slice_limit(unsigned long long bytes) {
+    g_slice_limit = bytes ? bytes : (1ull << 32);
     return VRWKV_OK;
 }
 
@@ -143,25 +152,37 @@ int vrwkv_wkv7_backward_bf16(int B, int T, int H, const void* w, const void* q, 
         misaligned(dy) || misaligned(s) || misaligned(sa) || misaligned(dw) || misaligned(dq) || misaligned(dk) ||
         misaligned(dv) || misaligned(dz) || misaligned(da))
         return VRWKV_EALIGN;
-    const wkv7::BwdArgs p{T, H, (const uint16_t*)w, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,
-                          (const uint16_t*)z, (const uint16_t*)a, (const uint16_t*)dy, s, sa,
-                          (uint16_t*)dw, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, (uint16_t*)dz, (uint16_t*)da};
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)((long)B * H));
     int var = resolve_bwd((long)B * H, g_bwd_variant.load());
-    const bool fits32 = (unsigned long long)B * T * H * 64ull * 4ull < (1ull << 32);      // wkv7_bwd_v8.h uses 32-bit byte offsets inside a tensor
-    if (!fits32 && var >= 8) var = 6;
+    // batch slices for the 32-bit offsets of wkv7_bwd_v8.h (see g_slice_limit)
+    const unsigned long long per_sample = (unsigned long long)T * H * 64ull * 4ull, limit = g_slice_limit.load();
+    int bmax = B;
+    if (var >= 8 && var <= 9 && (unsigned long long)B * per_sample >= limit) {
+        bmax = (int)((limit - 1) / per_sample);
+        if (bmax < 1) { var = 5; bmax = B; }
+    }
     g_last_bwd = var;
+    const size_t act = (size_t)T * H * 64, ckpt = (size_t)H * (T / VRWKV_CHUNK_LEN) * 64 * 64;      // elements per sample
+    for (int b0 = 0; b0 < B; b0 += bmax) {
+        const int nb = B - b0 < bmax ? B - b0 : bmax;
+        const size_t o = (size_t)b0 * act;
+        const wkv7::BwdArgs p{T, H, (const uint16_t*)w + o, (const uint16_t*)q + o, (const uint16_t*)k + o, (const uint16_t*)v + o,
+                              (const uint16_t*)z + o, (const uint16_t*)a + o, (const uint16_t*)dy + o, s + (size_t)b0 * ckpt, sa + o,
+                              (uint16_t*)dw + o, (uint16_t*)dq + o, (uint16_t*)dk + o, (uint16_t*)dv + o, (uint16_t*)dz + o, (uint16_t*)da + o};
+        const dim3 grid((unsigned)((long)nb * H));
+        int rc2;
 #ifdef VRWKV_V6_EXPERIMENTS
-    if (wkv7exp::is_experiment(var)) return wkv7exp::launch(var, grid, st, p);
+        if (wkv7exp::is_experiment(var)) rc2 = wkv7exp::launch(var, grid, st, p); else
 #endif
-    if (var == 9)        // score pieces a step ahead on the P waves
-        return launch_lds(&wkv7v8::bwd_kernel_v8<false, VRWKV_V8_PI, VRWKV_V8_PJ, VRWKV_V8_PP, 0, true, VRWKV_V8_PP, true>, grid, dim3(768), sizeof(wkv7v8::LdsV8), st, p);
-    if (var == 8)        // one copy of dL/dS, T chain on P wave 0, full-row memory role, 12 waves (wkv7_bwd_v8.h)
-        return launch_lds(&wkv7v8::bwd_kernel_v8<false>, grid, dim3(768), sizeof(wkv7v8::LdsV8), st, p);
-    if (var == 6)        // three-stage wave pipeline, 12 waves (wkv7_bwd_v6.h)
-        return launch_lds(&wkv7v6::bwd_kernel_v6<false>, grid, dim3(768), sizeof(wkv7v6::LdsV6), st, p);
-    return launch_lds(&wkv7v5::bwd_kernel_v5<false, BWD_V5_MODE>, grid, dim3(512), sizeof(wkv7v5::LdsV5), st, p);       // second-generation schedule (wkv7_bwd_v5.h)
+        if (var == 9)        // score pieces a step ahead on the P waves
+            rc2 = launch_lds(&wkv7v8::bwd_kernel_v8<false, true>, grid, dim3(768), sizeof(wkv7v8::LdsV8), st, p);
+        else if (var == 8)   // one copy of dL/dS, T chain on P wave 0, full-row memory role, 12 waves (wkv7_bwd_v8.h)
+            rc2 = launch_lds(&wkv7v8::bwd_kernel_v8<false>, grid, dim3(768), sizeof(wkv7v8::LdsV8), st, p);
+        else                 // second-generation schedule, 64-bit addressing (wkv7_bwd_v5.h)
+            rc2 = launch_lds(&wkv7v5::bwd_kernel_v5<false, BWD_V5_MODE>, grid, dim3(512), sizeof(wkv7v5::LdsV5), st, p);
+        if (rc2) return rc2;
+    }
+    return VRWKV_OK;
 }
 
 int vrwkv_wkv7_backward_segments_bf16(int B, int T, int H, int nseg, const void* w, const void* q, const void* k, const void* v,

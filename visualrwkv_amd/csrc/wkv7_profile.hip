@@ -13,13 +13,10 @@
 #ifndef VRWKV_PROF_AHEAD
 #define VRWKV_PROF_AHEAD false      // the v8 entry stamps variant 8; -DVRWKV_PROF_AHEAD=true: variant 9's schedule
 #endif
-#ifndef VRWKV_PROF_JTAIL
-#define VRWKV_PROF_JTAIL false      // -DVRWKV_PROF_JTAIL=true: the tail on the J waves (experiment variants 10 / 11)
-#endif
 
 using namespace wkv7launch;
 
-// backward: 0 = forward (the default kernel for the size), 1 = wkv7_bwd_v5.h, 2 = wkv7_bwd_v6.h, 4 = wkv7_bwd_v8.h; experiment builds: 3 = v7,
+// backward: 0 = forward (the default kernel for the size), 1 = wkv7_bwd_v5.h, 4 = wkv7_bwd_v8.h; experiment builds: 2 = the round-3 kernel, 3 = v7,
 // 20 + mask = v6 with roles switched off
 extern "C" int vrwkv_wkv7_profile_bf16(int backward, int B, int T, int H, const void* w, const void* q, const void* k, const void* v,
                                        const void* z, const void* a, const void* dy, void* y, float* s, float* sa,
@@ -43,10 +40,11 @@ extern "C" int vrwkv_wkv7_profile_bf16(int backward, int B, int T, int H, const 
     if (backward == 3 || (backward >= 20 && backward < 28)) return wkv7exp::launch_profile(backward, grid, st, p);
 #endif
     if (backward == 4)       // wkv7_bwd_v8.h: same stamps as v6
-        return launch_lds(&wkv7v8::bwd_kernel_v8<true, VRWKV_V8_PI, VRWKV_V8_PJ, VRWKV_V8_PP, 0, true, VRWKV_V8_PP, VRWKV_PROF_AHEAD, VRWKV_PROF_JTAIL>, grid, dim3(768),
-                          sizeof(wkv7v8::LdsV8), st, p);
-    if (backward == 2)       // three-stage pipeline (wkv7_bwd_v6.h): I / J / P wave 0, five stamps each
+        return launch_lds(&wkv7v8::bwd_kernel_v8<true, VRWKV_PROF_AHEAD>, grid, dim3(768), sizeof(wkv7v8::LdsV8), st, p);
+#ifdef VRWKV_V6_EXPERIMENTS
+    if (backward == 2)       // three-stage pipeline (benchmarks/experiments/wkv7_bwd_v6_kernel.h): I / J / P wave 0, five stamps each
         return launch_lds(&wkv7v6::bwd_kernel_v6<true>, grid, dim3(768), sizeof(wkv7v6::LdsV6), st, p);
+#endif
     if (backward == 1) return launch_lds(&wkv7v5::bwd_kernel_v5<true, BWD_V5_MODE>, grid, dim3(512), sizeof(wkv7v5::LdsV5), st, p);
     return VRWKV_EINVAL;
 }

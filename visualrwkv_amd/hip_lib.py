@@ -45,6 +45,7 @@ PROTOTYPES = {
     "vrwkv_wkv7_set_forward_variant": (_c_int, [_c_int]),
     "vrwkv_wkv7_set_backward_variant": (_c_int, [_c_int]),
     "vrwkv_wkv7_last_variant": (_c_int, [_c_int]),
+    "vrwkv_wkv7_set_backward_slice_limit": (_c_int, [ctypes.c_ulonglong]),
     "vrwkv_wkv7_resolve_variant": (_c_int, [_c_int] * 4),
     "vrwkv_mix_fwd_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int, _c_int] + [_c_void_p] * 4),
     "vrwkv_mix_fwd_prev_bf16": (_c_int, [ctypes.c_long, _c_int, _c_int, _c_int] + [_c_void_p] * 5),
