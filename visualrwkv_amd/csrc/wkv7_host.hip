@@ -19,6 +19,7 @@
 #include <functional>
 #include <mutex>
 #include <new>
+#include <pthread.h>
 #include <thread>
 #include <vector>
 
@@ -58,6 +59,7 @@ class Pool {
         int n_tasks = 0, active = 0, wanted = 0;
         unsigned long epoch = 0;
         bool stop = false;
+        long pid = 0;                                              // the process that created this state (published with it: one atomic pointer)
     };
 public:
     static Pool& get() { static Pool p; return p; }
@@ -84,10 +86,13 @@ public:
         s->fn = nullptr;
     }
 private:
-    Pool() = default;
+    Pool() { pthread_atfork(nullptr, nullptr, &Pool::after_fork_in_child); }
+    // the child of a fork() has one thread: whoever held the swap flag in the parent does not exist here, so release it (the state itself is
+    // recognised as the parent's by its pid and replaced on first use)
+    static void after_fork_in_child() { Pool::get().swap_.store(false, std::memory_order_release); }
     ~Pool() {
         State* s = st_.load();
-        if (!s || pid_.load() != (long)getpid()) return;           // a forked child never joins the parent's threads
+        if (!s || s->pid != (long)getpid()) return;                // a forked child never joins the parent's threads
         { std::lock_guard<std::mutex> lk(s->mu); s->stop = true; ++s->epoch; }
         s->cv.notify_all();
         for (auto& t : s->workers) if (t.joinable()) t.join();
@@ -97,13 +102,13 @@ private:
     State* state() {
         const long me = (long)getpid();
         State* s = st_.load(std::memory_order_acquire);
-        if (s && pid_.load(std::memory_order_acquire) == me) return s;
-        while (swap_.exchange(true, std::memory_order_acquire)) std::this_thread::yield();      // not a std::mutex: one held across a fork stays held in the child
-        s = st_.load();
-        if (!s || pid_.load() != me) {
+        if (s && s->pid == me) return s;                            // pid and state travel together: no window in which a reader pairs one with the other's
+        while (swap_.exchange(true, std::memory_order_acquire)) std::this_thread::yield();      // not a std::mutex: one held across a fork stays held in the child (the flag is reset by the atfork handler)
+        s = st_.load(std::memory_order_acquire);
+        if (!s || s->pid != me) {
             State* fresh = new (std::nothrow) State;               // the old one (if any) is the parent's: abandoned, not destroyed
+            if (fresh) fresh->pid = me;
             st_.store(fresh, std::memory_order_release);
-            pid_.store(me, std::memory_order_release);
             s = fresh;
         }
         swap_.store(false, std::memory_order_release);
@@ -136,7 +141,6 @@ private:
         }
     }
     std::atomic<State*> st_{nullptr};
-    std::atomic<long> pid_{0};
     std::atomic<bool> swap_{false};
 };
 
