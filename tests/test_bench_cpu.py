@@ -45,6 +45,12 @@ def test_bench_starts_its_own_ranks_two_gloo_ranks_on_host_cores():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["ranks_seen_by_collective"] == 2 and rec["config"]["parallelism"] == "dp2"
     assert rec["config"]["global_batch"] == 4 and rec["value"] > 0 and 5.0 < rec["config"]["loss"] < 12.5
+    # the N > 1 self-description of the line: what one rank processed, which collectives ran, and that `value` is the whole job's
+    pr = rec["per_rank"]
+    assert pr["ranks"] == 2 and pr["micro_bsz"] == 2 and pr["tokens_per_step"] == 2 * rec["config"]["seq_len"]
+    assert abs(rec["value"] - 2 * pr["tokens_per_step"] * rec["steps"] / (rec["ms_per_step"] * 1e-3 * rec["steps"])) < 1e-6 * rec["value"]
+    assert "reduce-scatter" in pr["data_path_collectives"] and "comm" in rec          # comm: stream-event timeline, GPU runs only
+    assert "1 = the reference's --grad_cp 1" in rec["config"]["grad_cp_meaning"]
 
 
 def test_baseline_config_1_end_to_end_on_host_cores():
