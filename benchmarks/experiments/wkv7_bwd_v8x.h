@@ -240,14 +240,14 @@ DEVFN Prep8 prep8(ChunkImg7& B, const RawP& raw, int c16, int j0, const LaneAddr
     if (c16 == 15) *reinterpret_cast<float4*>(&B.cl[j0]) = make_float4(o.cc[0], o.cc[1], o.cc[2], o.cc[3]);
     return o;
 }
-template <bool NOSTORE = false, bool NTST = false>
+template <bool NOSTORE = false, bool NTST = false, bool WIDE = false>
 DEVFN void tail8(LdsV8& lds, int par, const TailQ& tr, const BwdArgs& p, size_t u, unsigned lane_boff, int c16, int pw, int g, const LaneAddr& la) {
     const float4 zt4 = *reinterpret_cast<const float4*>(&lds.res[0][la.f32]);
     const float4 qt4 = *reinterpret_cast<const float4*>(&lds.res[1][la.f32]);
     const float4 ah4 = *reinterpret_cast<const float4*>(&lds.res[2][la.f32]);
     const float4 kh4 = *reinterpret_cast<const float4*>(&lds.res[3][la.f32]);
     const float4 gl4 = *reinterpret_cast<const float4*>(&lds.glast[par][16 * pw + 4 * g]);
-    lds_flag_add(&lds.flag[4]);                           // (waits for the reads above) the J waves may overwrite `res`
+    if (!WIDE) lds_flag_add(&lds.flag[4]);                // (waits for the reads above) the J waves may overwrite `res`  (WIDE: after the read-back)
     const float dZt[4] = {zt4.x, zt4.y, zt4.z, zt4.w}, dQt[4] = {qt4.x, qt4.y, qt4.z, qt4.w};
     const float dAh[4] = {ah4.x, ah4.y, ah4.z, ah4.w}, dKh[4] = {kh4.x, kh4.y, kh4.z, kh4.w};
     const float glv[4] = {gl4.x, gl4.y, gl4.z, gl4.w};
@@ -270,6 +270,20 @@ DEVFN void tail8(LdsV8& lds, int par, const TailQ& tr, const BwdArgs& p, size_t 
         lds.glast[par][16 * pw + 4 * g] = dw[0] + dq[1] + dk[2] + dz[3] + da[0];
         return;
     }
+    if (WIDE) {
+        // OPT & 8192, full-row stores: the five 8-byte results go back INTO the 16-byte slots of `res` this lane has just read (its own bytes: no hazard
+        // with the other P waves' reads) -- array k = 0 .. 3 in half (c16 & 1) of the slot in res[k], the fifth in the other half of the slot in res[0] --
+        // and wide_store() sends them out as whole 128-byte token rows once all four P waves have written (flag 7).  Token parity picks the half so that
+        // the read-back's 32-lane groups (4 tokens x 8 octets) spread over both halves.
+        const int h8 = 2 * (c16 & 1);                                   // in floats
+        *reinterpret_cast<uint2*>(&lds.res[0][la.f32 + h8]) = make_uint2(cvt_pk_bf16(dw[0], dw[1]), cvt_pk_bf16(dw[2], dw[3]));
+        *reinterpret_cast<uint2*>(&lds.res[1][la.f32 + h8]) = make_uint2(cvt_pk_bf16(dq[0], dq[1]), cvt_pk_bf16(dq[2], dq[3]));
+        *reinterpret_cast<uint2*>(&lds.res[2][la.f32 + h8]) = make_uint2(cvt_pk_bf16(dk[0], dk[1]), cvt_pk_bf16(dk[2], dk[3]));
+        *reinterpret_cast<uint2*>(&lds.res[3][la.f32 + h8]) = make_uint2(cvt_pk_bf16(dz[0], dz[1]), cvt_pk_bf16(dz[2], dz[3]));
+        *reinterpret_cast<uint2*>(&lds.res[0][la.f32 + 2 - h8]) = make_uint2(cvt_pk_bf16(da[0], da[1]), cvt_pk_bf16(da[2], da[3]));
+        lds_flag_add(&lds.flag[7]);
+        return;
+    }
     if (NTST) {
         typedef unsigned long long u64_;
         auto pk = [](uint32_t a, uint32_t b) { return (u64_)a | ((u64_)b << 32); };
@@ -285,6 +299,26 @@ DEVFN void tail8(LdsV8& lds, int par, const TailQ& tr, const BwdArgs& p, size_t 
     *out(p.dk) = make_uint2(cvt_pk_bf16(dk[0], dk[1]), cvt_pk_bf16(dk[2], dk[3]));
     *out(p.dz) = make_uint2(cvt_pk_bf16(dz[0], dz[1]), cvt_pk_bf16(dz[2], dz[3]));
     *out(p.da) = make_uint2(cvt_pk_bf16(da[0], da[1]), cvt_pk_bf16(da[2], da[3]));
+}
+
+// OPT & 8192: the read-back of tail8<WIDE>: 10 units of 8 token rows x 128 B (array k = unit >> 1, token half = unit & 1), units w, w + 4, w + 8 of P wave w;
+// lane = (token 8 half + (lane >> 3), octet lane & 7): two 8-byte pieces (4-channel groups 2o, 2o + 1) from the slots their owners wrote, one 16-byte store
+DEVFN void wide_store(LdsV8& lds, const BwdArgs& p, size_t u, unsigned ts, int lane, int w) {
+    uint16_t* const outs[5] = {p.dw, p.dq, p.dk, p.dz, p.da};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int unit = w + 4 * i;
+        if (unit < 10) {
+            const int k = unit >> 1, t = 8 * (unit & 1) + (lane >> 3), o = lane & 7;
+            const int half = k < 4 ? (t & 1) : 1 - (t & 1);
+            const float* img = lds.res[k < 4 ? k : 0];
+            const uint2 a = *reinterpret_cast<const uint2*>(&img[f32_off(t, 8 * o) + 2 * half]);
+            const uint2 b = *reinterpret_cast<const uint2*>(&img[f32_off(t, 8 * o + 4) + 2 * half]);
+            typedef uint32_t u4_ __attribute__((ext_vector_type(4)));
+            const u4_ v = {a.x, a.y, b.x, b.y};
+            *reinterpret_cast<u4_*>(outs[k] + u + (size_t)t * ts + 8 * o) = v;
+        }
+    }
 }
 
 // The same tail on the J waves (JTAIL): dZt dQt dAh dKh stay in registers (lane = token c16, 4 channels 16w + 4g ..), the operands of
@@ -385,7 +419,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
         const unsigned lane_boff = out_off * 2u;
         const DmaLane dl = dma_lane(lane, ts);
         const LeanLane ll = lean_lane(lane, w > 0 ? w - 1 : 0, ts);
-        unsigned n_ps = 0;
+        unsigned n_ps = 0, n_wide = 0;
         // One step.  FULL (steps 3 .. nchunk-2: a tail, a prep, a T, a non-empty S0 and a next chunk every time) has no
         // conditions: every path issues [6 row DMAs, 5-6 S0 DMAs (waves 1-3), 5 tail stores] in this order, so the wait before the
         // barrier is vmcnt(5): everything the other roles will read has landed, the stores stay in flight.
@@ -438,7 +472,9 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                         if (w == 1) s0_lean<0, CPS>(lds, sc, ll); else if (w == 2) s0_lean<1, CPS>(lds, sc, ll); else if (w == 3) s0_lean<2, CPS>(lds, sc, ll);
                     } else if (cd >= 0 && cd <= nchunk - 1) dma_state(lds.s0, cd > 0 ? sbase + (size_t)(cd - 1) * N * N : nullptr, k0, k1, lane);
                 }
-                if (!JTAIL && (FULL || (ct >= 0 && ct <= nchunk - 1))) tail8<(OPT & 64) != 0, (OPT & 4096) != 0>(lds, ct & 1, qt, p, head_base + (size_t)ct * L * ts, lane_boff, c16, w, g, la);
+                constexpr bool WIDE = (OPT & 8192) != 0;
+                const bool do_tail = !JTAIL && (FULL || (ct >= 0 && ct <= nchunk - 1));
+                if (do_tail) tail8<(OPT & 64) != 0, (OPT & 4096) != 0, WIDE>(lds, ct & 1, qt, p, head_base + (size_t)ct * L * ts, lane_boff, c16, w, g, la);
                 WKV_STAMP(0)
                 if (SHIFT && !JTAIL) { q2 = q1; q1 = q0; }
                 TailQ& qn = SHIFT ? q0 : qt;
@@ -462,8 +498,15 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                     if (n >= 1) lds_flag_wait(&lds.flag[0], 4u * (unsigned)n);
                     wkv7v6::scores6<true>(lds, lds.b[cp % 3], w, c16, g, la);
                 }
+                if (WIDE && do_tail) {                          // after the score pieces: by then wave 0 (T chain first) has written its quarter too
+                    n_wide += 4u;
+                    lds_flag_wait(&lds.flag[7], n_wide);        // all four P waves' results are in the image
+                    wide_store(lds, p, head_base + (size_t)ct * L * ts, ts, lane, w);
+                    lds_flag_add(&lds.flag[4]);                 // (waits for the reads) the J waves may overwrite `res`
+                }
                 WKV_STAMP(1)
-                if (FULL && !JTAIL && !(OPT & 64)) vmem_wait<5>(); else vmem_drain();      // JTAIL: this role issues requests only
+                if (FULL && !JTAIL && (OPT & 8192)) { if (w < 2) vmem_wait<3>(); else vmem_wait<2>(); }
+                else if (FULL && !JTAIL && !(OPT & 64)) vmem_wait<5>(); else vmem_drain();      // JTAIL: this role issues requests only
             } else if (w == 0 && cd >= 0 && cd <= nchunk - 1) lds_flag_add(&lds.flag[2]);
             WKV_STAMP(2)
             block_sync_lds();
