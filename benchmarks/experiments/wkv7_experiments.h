@@ -16,7 +16,7 @@
 namespace wkv7exp {
 using namespace wkv7launch;
 
-inline bool is_experiment(int var) { return var == 6 || var == 7 || var == 10 || var == 11 || (var >= 20 && var <= 39) || (var > 60 && var < 68) || (var > 70 && var < 78) || (var > 80 && var < 89); }
+inline bool is_experiment(int var) { return var == 6 || var == 7 || var == 10 || var == 11 || (var >= 20 && var <= 49) || (var > 60 && var < 68) || (var > 70 && var < 78) || (var > 80 && var < 89); }
 
 inline int launch(int var, dim3 grid, hipStream_t st, const wkv7::BwdArgs& p) {
     void (*kern)(wkv7::BwdArgs) = nullptr;
@@ -33,6 +33,10 @@ inline int launch(int var, dim3 grid, hipStream_t st, const wkv7::BwdArgs& p) {
         // cache policy of the requests (rows: bits 8-9, S0: bits 10-11; 1 nt, 2 sc1, 3 sc0 sc1 nt) and non-temporal tail stores (4096)
         VRWKV_OPT_CASE(30, 256) VRWKV_OPT_CASE(31, 1024) VRWKV_OPT_CASE(32, 1280) VRWKV_OPT_CASE(33, 2048) VRWKV_OPT_CASE(34, 3072) VRWKV_OPT_CASE(35, 4096) VRWKV_OPT_CASE(36, 4096 + 1280) VRWKV_OPT_CASE(37, 512 + 2048) VRWKV_OPT_CASE(38, 8192)     /* 38: full-row tail stores through the `res` slots */
 #undef VRWKV_OPT_CASE
+        // static wave priorities of the three roles (I, J, P; the product: 0, 0, 1) on variant 9
+#define VRWKV_PRIO_CASE(v, pi, pj, pp) case v: kern = &wkv7v8x::bwd_kernel_v8<false, pi, pj, pp, 0, true, pp, true, false, 0>; break;
+        VRWKV_PRIO_CASE(40, 0, 1, 1) VRWKV_PRIO_CASE(41, 1, 0, 1) VRWKV_PRIO_CASE(42, 0, 0, 0) VRWKV_PRIO_CASE(43, 0, 0, 2) VRWKV_PRIO_CASE(44, 1, 1, 2) VRWKV_PRIO_CASE(45, 0, 2, 1) VRWKV_PRIO_CASE(46, 1, 2, 0)
+#undef VRWKV_PRIO_CASE
 #define VRWKV_ROLE_CASES(base, KERN, LDS, ...)                                                        \
         case base + 1: kern = &KERN<false, __VA_ARGS__ 1>; lds = sizeof(LDS); break;   /* no P */        \
         case base + 2: kern = &KERN<false, __VA_ARGS__ 2>; lds = sizeof(LDS); break;   /* no I */        \
