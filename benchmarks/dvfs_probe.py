@@ -55,12 +55,12 @@ def run(B=16, T=2624, H=32, iters=20):
             return best
         fwd()
         rec = {"fwd_ms": round(t(fwd), 4), "bwd_ms": round(t(bwd), 4)}
-        # shader clock during the backward (profiling build of the SAME kernel generation, wkv7_bwd_v6.h): cycles of workgroup 0's
+        # shader clock during the backward (profiling build of the product kernel, wkv7_bwd_v8.h; until round 5 this probe stamped the round-3 kernel): cycles of workgroup 0's
         # I wave 0 over its life / that life in 10 ns ticks of the constant 100 MHz counter
         dbg = torch.zeros(32, dtype=torch.int64, device=dev)
         for _ in range(3):
             dbg.zero_()
-            assert lib.vrwkv_wkv7_profile_bf16(2, B, T, H, *[t_.data_ptr() for t_ in (w, q, k, v, z, a, dy, y, s, sa, *g)], dbg.data_ptr(), st) == 0
+            assert lib.vrwkv_wkv7_profile_bf16(4, B, T, H, *[t_.data_ptr() for t_ in (w, q, k, v, z, a, dy, y, s, sa, *g)], dbg.data_ptr(), st) == 0
             torch.cuda.synchronize()
         d = dbg.cpu().tolist()
         if d[15] > 0:
