@@ -210,6 +210,25 @@ def cpu_baseline(n_embd, T):
                       f"runs after 1 warm-up, {t:.2f} s per block, scaled x24; head/loss/ViT/optimizer not included"}
 
 
+class _StdoutToStderr:
+    """Route file descriptor 1 to descriptor 2 for the duration: the collective library prints a version banner with C stdio on stdout (flushed when
+    the process exits, i.e. AFTER the JSON line); stdout of this program is the one JSON line of rank 0 and nothing else."""
+
+    def __enter__(self):
+        import ctypes
+        sys.stdout.flush()
+        self._libc = ctypes.CDLL(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        self._libc.fflush(None)          # whatever C stdio buffered for "stdout" goes where fd 1 points now: stderr
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def _wkv7_kernel_name(backward: int, B: int, T: int, H: int) -> str:
     """The kernel a WKV7 launch of this shape resolves to (vrwkv_wkv7_resolve_variant: a pure function of the shape and the A/B override --
     the launches themselves come from two threads, the Python thread and autograd's): what the roofline entry is about.
@@ -288,13 +307,14 @@ def main():
     if world > 1 or os.environ.get("VRWKV_FORCE_COLLECTIVES") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if cpu_mode:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        ones = torch.ones(1, device=dev)
-        dist.all_reduce(ones)                       # the number of ranks the collective library actually connected
-        ranks_seen = int(ones.item())
+        with _StdoutToStderr():
+            if cpu_mode:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            ones = torch.ones(1, device=dev)
+            dist.all_reduce(ones)                       # the number of ranks the collective library actually connected
+            ranks_seen = int(ones.item())
         assert ranks_seen == dist.get_world_size() == world, (ranks_seen, dist.get_world_size(), world)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
@@ -462,6 +482,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.n_embd, a.ctx_len)
         print(json.dumps(out))
     if dist.is_initialized():
+        sys.stdout.flush()
+        os.dup2(2, 1)                                # anything the collective library still prints (its banner is flushed at exit) goes to stderr
         dist.destroy_process_group()
 
 
