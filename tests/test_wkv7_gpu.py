@@ -284,6 +284,41 @@ def test_backward_batch_slices(hip_lib, dev):
         hip_lib.vrwkv_wkv7_set_backward_slice_limit(0)
 
 
+def test_backward_of_a_4gib_launch_equals_its_unsliced_halves(hip_lib, dev):
+    """A REAL launch above the 32-bit offset limit: B = 8, T = 65536, H = 32 -- `sa` is exactly 4 GiB, so the launcher cuts the batch into slices of
+    7 + 1 samples (512 MiB of `sa` each).  Too large for the CPU oracle; the property: every sample's gradients are bit-identical to those of the same
+    sample in a launch of 4 (2 GiB: no slicing, offsets far from the limit) -- the batch is a pure outer loop of the operator.  ~50 GB of device memory."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * 2**30:
+        pytest.skip("needs ~50 GB of device memory")
+    B, T, H = 8, 65536, 32
+    assert B * T * H * 64 * 4 >= 1 << 32
+    g = torch.Generator(device=dev).manual_seed(5)
+    shape = (B, T, H, 64)
+    rnd = lambda scale: (torch.randn(shape, device=dev, generator=g, dtype=torch.float32) * scale)
+    w = (-torch.nn.functional.softplus(-rnd(1.0)) - 0.5).bfloat16()            # w_raw <= -0.5 (src/model.py:176)
+    kk = torch.nn.functional.normalize(rnd(1.0), dim=-1)
+    z = (-kk).bfloat16()
+    a = (kk * torch.sigmoid(rnd(1.0))).bfloat16()
+    del kk
+    q, k, v, dy = rnd(0.5).bfloat16(), rnd(0.5).bfloat16(), rnd(0.5).bfloat16(), rnd(0.1).bfloat16()
+    d = [w, q, k, v, z, a, dy]
+    y, s, sa = _capi_forward(hip_lib, *d[:6])
+    full = _capi_backward(hip_lib, *d, s, sa)
+    assert hip_lib.vrwkv_wkv7_last_variant(1) == 8                          # B x H = 256: one round of workgroups per slice
+    torch.cuda.synchronize()
+    yh, sh, sah = _capi_forward(hip_lib, *[t[4:] for t in d[:6]])           # the forward addresses with 64 bits: the last four samples alone give the same bits
+    assert torch.equal(yh, y[4:]) and torch.equal(sh, s[4:]) and torch.equal(sah, sa[4:])
+    del yh, sh, sah
+    for b0 in (0, 4):
+        sl = slice(b0, b0 + 4)
+        half = _capi_backward(hip_lib, *[t[sl] for t in d], s[sl], sa[sl])
+        torch.cuda.synchronize()
+        for n, x, r in zip(NAMES, full, half):
+            assert torch.equal(x[sl], r), (n, b0)
+            assert bool(torch.isfinite(r.float()).all()), n
+
+
 def _capi_forward_state(lib, w, q, k, v, z, a, s0=None, want_final=True, by_products=False):
     B, T, H, N = w.shape
     y = torch.empty_like(v)
