@@ -304,10 +304,17 @@ def test_backward_of_a_4gib_launch_equals_its_unsliced_halves(hip_lib, dev):
     q, k, v, dy = rnd(0.5).bfloat16(), rnd(0.5).bfloat16(), rnd(0.5).bfloat16(), rnd(0.1).bfloat16()
     d = [w, q, k, v, z, a, dy]
     y, s, sa = _capi_forward(hip_lib, *d[:6])
+    assert hip_lib.vrwkv_wkv7_last_variant(0) == 7
     full = _capi_backward(hip_lib, *d, s, sa)
     assert hip_lib.vrwkv_wkv7_last_variant(1) == 8                          # B x H = 256: one round of workgroups per slice
     torch.cuda.synchronize()
-    yh, sh, sah = _capi_forward(hip_lib, *[t[4:] for t in d[:6]])           # the forward addresses with 64 bits: the last four samples alone give the same bits
+    # the forward addresses with 64 bits (16 GiB of checkpoints here): the last four samples alone -- the same kernel forced, 128 heads would get the
+    # two-workgroup split otherwise -- give the same bits
+    assert hip_lib.vrwkv_wkv7_set_forward_variant(7) == 0
+    try:
+        yh, sh, sah = _capi_forward(hip_lib, *[t[4:] for t in d[:6]])
+    finally:
+        hip_lib.vrwkv_wkv7_set_forward_variant(-1)
     assert torch.equal(yh, y[4:]) and torch.equal(sh, s[4:]) and torch.equal(sah, sa[4:])
     del yh, sh, sah
     for b0 in (0, 4):
