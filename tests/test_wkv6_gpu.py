@@ -280,3 +280,40 @@ def test_ddmix_and_gn_silu_kernels_against_fp32():
     assert rel_rms(out.detach().float(), reff.detach().bfloat16().float()) < 1e-3
     assert rel_rms(y.grad.float(), yf.grad) < 3e-3 and rel_rms(gg.grad.float(), ggf.grad) < 3e-3
     assert rel_rms(lnb.weight.grad.float(), lnf.weight.grad) < 5e-3 and rel_rms(lnb.bias.grad.float(), lnf.bias.grad) < 5e-3
+
+
+def test_backward_of_a_4gib_launch_equals_its_unsliced_halves():
+    """cfg 4's operator above the 32-bit offset limit of wkv6_bwd_v2.h: B = 4, T = 65536, H = 64 -- the fp32 decay tensor is exactly 4 GiB, so the launcher
+    cuts the batch into slices of 3 + 1 samples.  Property (too large for the oracle): every sample's gradients, and its per-sample bonus gradient gu,
+    are bit-identical to those of the same sample in a launch of 2 (2 GiB, unsliced).  ~40 GB of device memory."""
+    from visualrwkv_amd import wkv6
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * 2**30:
+        pytest.skip("needs ~40 GB of device memory")
+    B, T, H = 4, 65536, 64
+    C = H * 64
+    assert B * T * C * 4 >= 1 << 32
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(11)
+    rnd = lambda scale: (torch.randn(B, T, C, device=dev, generator=g, dtype=torch.float32) * scale).bfloat16()
+    r, k, v, gy = rnd(0.5), rnd(0.5), rnd(0.5), rnd(0.1)
+    ew = -torch.exp(torch.randn(B, T, C, device=dev, generator=g, dtype=torch.float32) * 0.5 - 1.0)          # ew = -exp(w), as WKV_6.forward forms it
+    u = (torch.randn(C, device=dev, generator=g) * 0.3).bfloat16()
+    y = torch.empty(B, T, C, device=dev, dtype=torch.bfloat16)
+    ckpt = wkv6.ckpt_tensor(B, T, H, dev)
+    wkv6.forward_hip(B, T, C, H, r, k, v, ew, u, y, ckpt)
+
+    def bwd(sl):
+        n = sl.stop - sl.start
+        outs = [torch.empty(n, T, C, device=dev, dtype=torch.bfloat16) for _ in range(4)] + [torch.empty(n, C, device=dev, dtype=torch.bfloat16)]
+        wkv6.backward_hip(n, T, C, H, r[sl], k[sl], v[sl], ew[sl], u, gy[sl], *outs, ckpt.view(B, -1)[sl].reshape(-1))
+        torch.cuda.synchronize()
+        return outs
+
+    full = bwd(slice(0, 4))
+    for b0 in (0, 2):
+        sl = slice(b0, b0 + 2)
+        half = bwd(sl)
+        for name, x, h_ in zip(("gr", "gk", "gv", "gw", "gu"), full, half):
+            assert torch.equal(x[sl], h_), (name, b0)
+            assert bool(torch.isfinite(h_.float()).all()), name

@@ -52,18 +52,33 @@ int vrwkv_wkv6_backward_bf16(int B, int T, int C, int H, const void* r, const vo
     if (misaligned16(r) || misaligned16(k) || misaligned16(v) || misaligned16(ew) || misaligned16(u) || misaligned16(gy) ||
         misaligned16(s_ckpt) || misaligned16(gr) || misaligned16(gk) || misaligned16(gv) || misaligned16(gw) || misaligned16(gu))
         return VRWKV_EALIGN;
-    wkv6c::Bwd6Args p{T, H, (const uint16_t*)r, (const uint16_t*)k, (const uint16_t*)v, ew, (const uint16_t*)u,
-                      (const uint16_t*)gy, s_ckpt, (uint16_t*)gr, (uint16_t*)gk, (uint16_t*)gv, (uint16_t*)gw, (uint16_t*)gu};
-    const bool fits32 = (unsigned long long)B * T * C * 4ull < (1ull << 32);      // wkv6_bwd_v2.h forms 32-bit byte offsets (ew is fp32)
-    if (g_bwd6_variant == 1 || !fits32) {
-        hipLaunchKernelGGL(wkv6c::bwd6_kernel, dim3((unsigned)((long)B * H)), dim3(256), 0, (hipStream_t)stream, p);
-        return done6();
+    // wkv6_bwd_v2.h forms 32-bit byte offsets inside a tensor (the largest is the fp32 ew): a launch that reaches 4 GiB runs as batch slices of the
+    // same kernel on offset pointers (every tensor is batch-major; gu is per sample); one sample that large goes to the four-wave kernel (64-bit)
+    const unsigned long long per_sample = (unsigned long long)T * C * 4ull, limit = 1ull << 32;
+    int bmax = B;
+    bool v1 = g_bwd6_variant == 1;
+    if (!v1 && (unsigned long long)B * per_sample >= limit) {
+        bmax = (int)((limit - 1) / per_sample);
+        if (bmax < 1) { v1 = true; bmax = B; }
     }
     void (*kern)(wkv6c::Bwd6Args) = &wkv6v2::bwd6_kernel_v2;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv6v2::Lds6V2));
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((long)B * H)), dim3(768), sizeof(wkv6v2::Lds6V2), (hipStream_t)stream, p);
-    return done6();
+    if (!v1) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wkv6v2::Lds6V2));
+        if (e != hipSuccess) return (int)e;
+    }
+    const size_t act = (size_t)T * C, ck = (size_t)H * ((T + 15) / 16) * 64 * 64;
+    for (int b0 = 0; b0 < B; b0 += bmax) {
+        const int nb = B - b0 < bmax ? B - b0 : bmax;
+        const size_t o = (size_t)b0 * act;
+        wkv6c::Bwd6Args p{T, H, (const uint16_t*)r + o, (const uint16_t*)k + o, (const uint16_t*)v + o, ew + o, (const uint16_t*)u,
+                          (const uint16_t*)gy + o, s_ckpt + (size_t)b0 * ck, (uint16_t*)gr + o, (uint16_t*)gk + o, (uint16_t*)gv + o, (uint16_t*)gw + o,
+                          (uint16_t*)gu + (size_t)b0 * C};
+        if (v1) hipLaunchKernelGGL(wkv6c::bwd6_kernel, dim3((unsigned)((long)nb * H)), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(kern, dim3((unsigned)((long)nb * H)), dim3(768), sizeof(wkv6v2::Lds6V2), (hipStream_t)stream, p);
+        const int rc2 = done6();
+        if (rc2) return rc2;
+    }
+    return VRWKV_OK;
 }
 
 }  // extern "C"
