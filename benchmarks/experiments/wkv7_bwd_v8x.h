@@ -449,6 +449,11 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                     else if (w == 3) rows_lean<2, CPR>(lds, p, cp - 1, cb16, ll);
                 } else if (w > 0 && cp >= 1) dma_chunk<LdsV8, 3>(lds, p, head_base + (size_t)(cp - 1) * L * ts, cp - 1, w - 1, ts, dl);
                 Prep8 dd{};
+                if ((OPT & 32768) && FULL && w > 0) {           // S0 requested BEFORE the prepare: ~700 cycles more to land (the wait for it ends the step)
+                    lds_flag_wait(&lds.flag[3], 4u * (unsigned)(n - 1));
+                    const float* sc = sbase + (size_t)(cd - 1) * N * N;
+                    if (w == 1) s0_lean<0>(lds, sc, ll); else if (w == 2) s0_lean<1>(lds, sc, ll); else s0_lean<2>(lds, sc, ll);
+                }
                 if (AHEAD && w > 0 && do_prep) { dd = prep8(lds.b[cp % 3], raw, c16, 16 * w + 4 * g, la); lds_flag_add(&lds.flag[6]); }
                 // T = (I - M_za)^-1 of the I waves' chunk, from the images this role built a step ago: the doubling chain is 28
                 // dependent MFMA / split stages and nobody needs T before the I waves have formed dSA
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                 // S0 of chunk cd = s[cd-1] for the j-split of the next step, into the image the J waves have just left
                 {
                     const int k0 = w == 1 ? 0 : w == 2 ? 5 : 10, k1 = w == 0 ? 0 : w == 1 ? 5 : w == 2 ? 10 : 16;      // waves 1-3: 5 5 6 KB
-                    if (OPT & (128 | 4)) {
+                    if ((OPT & (128 | 4)) || ((OPT & 32768) && FULL)) {
                     } else if (FULL) {
                         const float* sc = sbase + (size_t)(cd - 1) * N * N;
                         constexpr int CPS = (OPT >> 10) & 3;     // cache policy of the S0 requests (experiment)
@@ -775,10 +780,11 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                     dul[kb] = mk8(lds_read_tr16(&lds.dsi[1][tro[kb][0]]), lds_read_tr16(&lds.dsi[1][tro[kb][1]]));
                 }
                 bf16x8 s0h[2], s0l[2];
+                if (OPT & 16384) lds_flag_add(&lds.flag[3]);    // the reads have returned (the add waits for them): hand S0 / the dS image back BEFORE the split's ~60 VALU instructions
                 tiles_op(S0, s0h, s0l);
                 if (OPT & 4) order_after(s0h[0], s0h[1], s0l[0], s0l[1]);      // the split has consumed the old contents
                 if (OPT & 4) ld_s0(sreg, (OPT & 16) ? cj - 1 : cj - 2);          // this set's next occupant: two steps to land (OPT & 16: one set, one step)
-                lds_flag_add(&lds.flag[3]);                 // (waits for the reads) S0 and the dS image may be overwritten
+                if (!(OPT & 16384)) lds_flag_add(&lds.flag[3]);                 // (waits for the reads) S0 and the dS image may be overwritten
                 WKV_STAMP(5)
                 // decay-gradient term of this chunk: sum_i dS[i][j] S_L[i][j] = diag((dU)^T S_L)[j] / c_L[j], S_L = the S0 of a step ago
                 {

@@ -58,6 +58,7 @@ int emu_wkv7_backward_chunked(int B, int T, int H, const void* w, const void* q,
     if (mode == 15) { emu::launch(grid, dim3(768), [&] { wkv7v8x::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, true, false, 4>(p); }); return (int)sizeof(wkv7v8x::LdsV8); }   // variant 9 + S0 by register prefetch in the J waves
     if (mode == 16) { emu::launch(grid, dim3(768), [&] { wkv7v8x::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, false, false, 4>(p); }); return (int)sizeof(wkv7v8x::LdsV8); }   // variant 8 + the same
     if (mode == 17) { emu::launch(grid, dim3(768), [&] { wkv7v8x::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, true, false, 8192>(p); }); return (int)sizeof(wkv7v8x::LdsV8); }   // variant 9 + full-row tail stores
+    if (mode == 18) { emu::launch(grid, dim3(768), [&] { wkv7v8x::bwd_kernel_v8<false, 0, 0, 1, 0, true, 1, true, false, 16384 + 32768>(p); }); return (int)sizeof(wkv7v8x::LdsV8); }   // variant 9 + early S0 hand-back + S0 requested before the prepare
     return -1;
 }
 

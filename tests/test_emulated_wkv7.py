@@ -62,7 +62,7 @@ def test_forward_from_state(emu_lib):
                                     (11, 16), (11, 32), (11, 48), (11, 64), (11, 80), (11, 160), (12, 16), (12, 32), (12, 48), (12, 64), (12, 80), (12, 160),
                                     (13, 16), (13, 48), (13, 80), (13, 160), (14, 16), (14, 48), (14, 80), (14, 160),
                                     (15, 16), (15, 32), (15, 48), (15, 64), (15, 80), (15, 160), (16, 16), (16, 32), (16, 48), (16, 80), (16, 160),
-                                    (17, 16), (17, 32), (17, 48), (17, 64), (17, 80), (17, 160)])
+                                    (17, 16), (17, 32), (17, 48), (17, 64), (17, 80), (17, 160), (18, 16), (18, 32), (18, 48), (18, 64), (18, 80), (18, 160)])
 def test_backward_chunked(emu_lib, mode, T):
     """Chunked MFMA backward kernels run lane-exactly on the host: 6 = the producer / consumer schedule (wkv7_bwd_v5.h), 7 = the three-stage wave pipeline (wkv7_bwd_v6.h;
     1, 2 and 6 chunks: pipeline shorter than, equal to and longer than its depth), 8 = the same pipeline with the full-row memory
@@ -71,7 +71,8 @@ def test_backward_chunked(emu_lib, mode, T):
     term as an MFMA diagonal, the T chain on P wave 0, single-buffered S0), 10 = 9 with the score pieces a step ahead on the P waves, 11 / 12 = 9 / 10 with
     the element-wise tail and the gradient stores on the J waves (JTAIL), 13 / 14 = 10 / 9 with the round-6 LDS layout (OPT = 3: tile-pair reads dealt over
     both halves of their slots, dS image swizzled with row bit 3), 15 / 16 = 10 / 9 with S0 prefetched into the J waves' registers (OPT = 4), 17 = 10 with the five tail outputs stored as whole
-    128-byte rows through the `res` slots (OPT = 8192) -- all bit-identical to 10 / 9."""
+    128-byte rows through the `res` slots (OPT = 8192), 18 = 10 with S0 handed back before the J waves' split and requested before the P waves' prepare -- all
+    bit-identical to 10 / 9."""
     B, H = 1, 2
     w, q, k, v, z, a, dy = make_inputs(B, T, H, seed=7 + mode)
     _, s, sa = wkv7_c.forward(w, q, k, v, z, a)
@@ -82,9 +83,9 @@ def test_backward_chunked(emu_lib, mode, T):
     assert 0 < lds <= 160 * 1024
     for name, o, r in zip(["dw", "dq", "dk", "dv", "dz", "da"], outs, ref):
         assert rel_rms(o.float(), r.float()) < 1e-3, (name, mode)
-    if mode in (13, 14, 15, 16, 17):    # a pure re-addressing of LDS / S0 from memory into the J waves' registers instead of through an LDS image: the same values reach the same MFMAs
+    if mode in (13, 14, 15, 16, 17, 18):    # a pure re-addressing of LDS / S0 from memory into the J waves' registers instead of through an LDS image: the same values reach the same MFMAs
         base = [torch.zeros_like(w) for _ in range(6)]
-        emu_lib.emu_wkv7_backward_chunked(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(dy), P(s), P(sa), *[P(o) for o in base], {13: 10, 14: 9, 15: 10, 16: 9, 17: 10}[mode])
+        emu_lib.emu_wkv7_backward_chunked(B, T, H, P(w), P(q), P(k), P(v), P(z), P(a), P(dy), P(s), P(sa), *[P(o) for o in base], {13: 10, 14: 9, 15: 10, 16: 9, 17: 10, 18: 10}[mode])
         for name, o, r in zip(["dw", "dq", "dk", "dv", "dz", "da"], outs, base):
             assert torch.equal(o, r), (name, mode)
 
