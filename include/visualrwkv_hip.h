@@ -189,7 +189,8 @@ int vrwkv_wkv7_step_bf16(int B, int H, const void* w, const void* q, const void*
 /* Kernel-generation override for tests and A/B benchmarks; -1 restores the default.
  * forward:  -1 = the default: csrc/wkv7_fwd_v4.h (chunked MFMA kernel with producer / consumer waves; rows in by LDS-DMA, results out
  *            through LDS images, 1 KB per store instruction) for B*H > 128, else the two-workgroups-per-head instantiation of
- *            csrc/wkv7_fwd_v3.h; 7 = wkv7_fwd_v4.h whatever the size; 1..5 = instantiations of wkv7_fwd_v3.h for A/B (4 = its default one).
+ *            csrc/wkv7_fwd_v3.h; 7 = wkv7_fwd_v4.h whatever the size; 6 = the two-workgroups-per-head form whatever the size; 1..5 = instantiations of wkv7_fwd_v3.h for A/B
+ *            (4 = its default one).  Measured at T = 2624, H = 32 (round 6): 128 heads 0.283 (6) vs 0.297 ms (7); 192 heads 0.452 vs 0.299; 256 heads 0.493 vs 0.319.
  * backward: -1 = the default (9 for B x H > 256, else 8; a launch whose `sa` reaches 4 GiB runs as batch slices of the same kernel), 9 = 8 with the score pieces of a chunk formed one step ahead by the
  *            memory-role waves in what was their barrier wait (0 ... -3 % against 8 at B = 4 ... 32, -2.3 % inside the training step), 8 = three-role
  *            pipeline of 12 waves with ONE copy of dL/dS (handed from the i-split to the j-split waves as an operand image), the T chain on a

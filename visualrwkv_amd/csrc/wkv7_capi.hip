@@ -42,7 +42,7 @@ std::atomic<unsigned long long> g_slice_limit{1ull << 32};
 // (the default instantiation of wkv7_fwd_v3.h: the others have no state arguments).
 int resolve_fwd(long heads, int forced, bool stateful) {
     if (forced == 7 || (forced == -1 && heads > FWD_ISPLIT_MAX_HEADS)) return 7;
-    if (forced == -1) return 6;
+    if (forced == -1 || forced == 6) return 6;
     return stateful ? 4 : forced;
 }
 // backward: variant 9 when the launch has more workgroups than the chip has CUs (measured -0.4 ... -2.3 % at B x H = 384 ... 1024), variant 8
@@ -65,7 +65,7 @@ const char* vrwkv_strerror(int code) {
 }
 
 int vrwkv_wkv7_set_forward_variant(int variant) {
-    if (variant != -1 && !(variant >= 1 && variant <= 5) && variant != 7) return VRWKV_EINVAL;   // 1..5: A/B instantiations of wkv7_fwd_v3.h; 7: wkv7_fwd_v4.h
+    if (variant != -1 && !(variant >= 1 && variant <= 7)) return VRWKV_EINVAL;   // 1..5: A/B instantiations of wkv7_fwd_v3.h; 6: its two-workgroups-per-head form; 7: wkv7_fwd_v4.h
     g_fwd_variant = variant;
     return VRWKV_OK;
 }
