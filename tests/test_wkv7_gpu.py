@@ -400,6 +400,25 @@ def test_recompute_state_autograd_surface_at_bench_size(hip_lib, dev):
         assert torch.equal(l.grad, l2.grad), n         # same kernels on the same inputs: bit-identical
 
 
+def test_forward_without_gradients_skips_the_by_products(hip_lib, dev):
+    """Under no_grad (the reference's evaluate.py / generate()) nobody consumes `s` and `sa`: WindBackstepping then runs the entry without them -- the same
+    kernel with null by-product pointers -- and returns the training forward's y bit for bit while allocating y only."""
+    from visualrwkv_amd import wkv7
+    B, T, H = 8, 1024, 32                                   # 256 heads: wkv7_fwd_v4.h on both paths
+    w, q, k, v, z, a, _ = [t.to(dev) for t in make_inputs(B, T, H, seed=17)]
+    leaves = [t.clone().requires_grad_(True) for t in (w, q, k, v, z, a)]
+    y_train = wkv7.WindBackstepping.apply(*leaves)
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    with torch.no_grad():
+        y_eval = wkv7.WindBackstepping.apply(w, q, k, v, z, a)
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated() - base <= y_eval.numel() * 2 + (1 << 20)        # no 20 B / element of checkpoints
+    assert torch.equal(y_eval, y_train.detach())
+    y_frozen = wkv7.WindBackstepping.apply(w, q, k, v, z, a)                              # grad mode on, but no input asks for a gradient
+    assert torch.equal(y_frozen, y_train.detach()) and not y_frozen.requires_grad
+
+
 def test_launches_from_two_threads(hip_lib, dev):
     """The op is called from the Python thread and from autograd's backward thread: two threads launching different shapes
     on their own streams at once both get right results, and vrwkv_wkv7_resolve_variant (a pure function) names each launch's kernel

@@ -213,7 +213,13 @@ class WindBackstepping(torch.autograd.Function):
         assert all(i.dtype == torch.bfloat16 or (i.dtype == torch.float32 and not i.is_cuda) for i in [w, q, k, v, z, b])
         assert all(i.is_contiguous() for i in [w, q, k, v, z, b])
         P = tparallel_segments(B, H, T, forward=True) if TPARALLEL_BWD and w.is_cuda else 1
-        ctx.recompute = bool(extra and extra[0] and w.is_cuda and w.dtype == torch.bfloat16 and P == 1)
+        hip_bf16 = w.is_cuda and w.dtype == torch.bfloat16 and P == 1
+        if hip_bf16 and not any(ctx.needs_input_grad[:6]):
+            # nobody will ask for a gradient (evaluate.py / generate() under no_grad, frozen inputs): the by-products `s` and `sa` -- 22 of the
+            # forward's 24 output bytes per element -- have no consumer, so the entry without them runs (same kernel, same y)
+            ctx.recompute = False
+            return wkv7_forward_state(w, q, k, v, z, b, None, want_state=False)[0]
+        ctx.recompute = bool(extra and extra[0] and hip_bf16)
         if ctx.recompute:                               # y only; the backward regenerates s and sa
             y, _ = wkv7_forward_state(w, q, k, v, z, b, None, want_state=False)
             ctx.save_for_backward(w, q, k, v, z, b)
