@@ -24,7 +24,11 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
 from .attention import attention, attention_relpos
+
+VIT_STREAMS = os.environ.get("VRWKV_VIT_STREAMS", "1") != "0"      # the towers of SamDinoSigLIPViTBackbone on one HIP stream each
 
 
 class _Mlp(nn.Module):
@@ -409,6 +413,7 @@ class SamDinoSigLIPViTBackbone(nn.Module):
     def __init__(self, vision_tower_path: Optional[dict] = None, default_image_size: int = 448,
                  towers: Sequence[str] = ("dino", "siglip", "sam"), tower_kwargs: Optional[Dict[str, dict]] = None):
         super().__init__()
+        self._streams = None
         tk = tower_kwargs or {}
         self.towers = tuple(towers)
         if "dino" in towers:
@@ -436,14 +441,32 @@ class SamDinoSigLIPViTBackbone(nn.Module):
             d += self.sam_featurizer.output_dim
         return d
 
-    def forward(self, pixel_values: Dict[str, torch.Tensor]) -> torch.Tensor:
-        feats = []
-        if "dino" in self.towers:
-            feats.append(self.dino_featurizer(pixel_values["dino"]))
-        if "siglip" in self.towers:
-            feats.append(self.siglip_featurizer(pixel_values["siglip"]))
-        if "sam" in self.towers:
+    def _tower(self, name, pixel_values):
+        if name == "sam":
             s = self.sam_featurizer(pixel_values["sam"])
             B, C, H, W = s.shape
-            feats.append(s.view(B, C, H * W).permute(0, 2, 1))
-        return torch.cat(feats, dim=2)
+            return s.view(B, C, H * W).permute(0, 2, 1)
+        return getattr(self, f"{name}_featurizer")(pixel_values[name])
+
+    def forward(self, pixel_values: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """Concatenated features of the towers (src/vision.py:123-134).  On the device and without autograd (the towers are frozen) the towers run
+        CONCURRENTLY, one HIP stream each: a tower's GEMMs have 16 384 rows x 1 024-1 152 columns = 320 tiles of 256 x 256 for 256 CUs, i.e. a full
+        round and a quarter-filled one, and the other tower's kernels take the idle CUs (VRWKV_VIT_STREAMS=0: one after the other)."""
+        names = [n for n in ("dino", "siglip", "sam") if n in self.towers]
+        x0 = pixel_values[names[0]]
+        if VIT_STREAMS and len(names) > 1 and x0.is_cuda and not torch.is_grad_enabled():
+            cur = torch.cuda.current_stream(x0.device)
+            if self._streams is None or self._streams[0].device != x0.device:
+                self._streams = [torch.cuda.Stream(device=x0.device) for _ in names[1:]]
+            outs = [None] * len(names)
+            for i, name in enumerate(names[1:], start=1):
+                st = self._streams[i - 1]
+                st.wait_stream(cur)                          # the pixels (and whatever wrote them) are ready
+                with torch.cuda.stream(st):
+                    outs[i] = self._tower(name, pixel_values)
+            outs[0] = self._tower(names[0], pixel_values)    # the first tower on the caller's stream
+            for i, st in enumerate(self._streams, start=1):
+                cur.wait_stream(st)
+                outs[i].record_stream(cur)                   # allocated on the side stream, consumed (and freed) on the caller's
+            return torch.cat(outs, dim=2)
+        return torch.cat([self._tower(n, pixel_values) for n in names], dim=2)
