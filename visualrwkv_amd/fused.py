@@ -98,6 +98,21 @@ VF_CHAIN = os.environ.get("VRWKV_VF_CHAIN", "1") != "0"          # A/B switch: 0
 FLAT_WGRAD = os.environ.get("VRWKV_FLAT_WGRAD", "1") != "0"      # A/B switch: 0 = weight gradients as fresh tensors, copied into the ZeRO-1 buffer
 
 
+# dgrad (library GEMM) and wgrad (csrc/wgrad_big.h) of one Linear on two HIP streams, joined before the node returns: both are whole-chip kernels whose LAST
+# round of workgroups is part-filled (C x C at 41 984 rows: 5.125 rounds of 256 x 256 tiles cost 6, profiles/r6h_gemm_tail_probe.jsonl), and a kernel of another
+# stream takes the idle CUs.  The streams never leave the autograd node, so what autograd and the ZeRO-1 hooks see is unchanged.  0 = one after the other.
+OVERLAP_WGRAD = os.environ.get("VRWKV_OVERLAP_WGRAD", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev, i=0):
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), i)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
 BIG_WGRAD = os.environ.get("VRWKV_BIG_WGRAD", "1") != "0"        # A/B switch: 0 = the library's "N,T" kernel for dW = dy^T x of the Linear layers
 
 
@@ -162,11 +177,68 @@ class _LinearTN(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dx = dw = None
+        if OVERLAP_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and dy.is_cuda:
+            dy = dy.contiguous()
+            cur, side = torch.cuda.current_stream(dy.device), _side_stream(dy.device)
+            side.wait_stream(cur)                                    # dy and x are ready
+            with torch.cuda.stream(side):
+                dw = _weight_grad(ctx.wparam, dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1]))
+            dx = F.linear(dy, transpose2d(w))
+            cur.wait_stream(side)                                    # joined: nothing of the side stream outlives this node
+            dw.record_stream(cur)
+            return dx, dw
         if ctx.needs_input_grad[0]:
             dx = F.linear(dy, transpose2d(w))
         if ctx.needs_input_grad[1]:
             dw = _weight_grad(ctx.wparam, dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1]))
         return dx, dw
+
+
+class _Linear3TN(torch.autograd.Function):
+    """Three independent bias-free Linear layers on three inputs -- receptance / key / value of the time-mix (src/model.py:175-178) -- as ONE autograd node
+    whose GEMMs run on three HIP streams (forward) and whose input-gradient and weight-gradient GEMMs run on two (backward), joined before the node
+    returns (see OVERLAP_WGRAD): each of these C x C GEMMs alone leaves 7/8 of its last round of tiles idle."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, x2, w0, w1, w2):
+        ctx.save_for_backward(x0, x1, x2, w0, w1, w2)
+        ctx.wparams = [w if hasattr(w, "_vrwkv_flat_grad") else None for w in (w0, w1, w2)]
+        cur = torch.cuda.current_stream(x0.device)
+        sides = [_side_stream(x0.device, 0), _side_stream(x0.device, 1)]
+        outs = [None, None, None]
+        for st, i, x, w in ((sides[0], 1, x1, w1), (sides[1], 2, x2, w2)):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs[i] = F.linear(x, w)
+        outs[0] = F.linear(x0, w0)
+        for st, i in ((sides[0], 1), (sides[1], 2)):
+            cur.wait_stream(st)
+            outs[i].record_stream(cur)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, d0, d1, d2):
+        x0, x1, x2, w0, w1, w2 = ctx.saved_tensors
+        dys = [d.contiguous() for d in (d0, d1, d2)]
+        cur, side = torch.cuda.current_stream(x0.device), _side_stream(x0.device)
+        side.wait_stream(cur)
+        dws = []
+        with torch.cuda.stream(side):
+            for wp, dy, x in zip(ctx.wparams, dys, (x0, x1, x2)):
+                dws.append(_weight_grad(wp, dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])))
+        dxs = [F.linear(dy, transpose2d(w)) for dy, w in zip(dys, (w0, w1, w2))]
+        cur.wait_stream(side)
+        for dw in dws:
+            dw.record_stream(cur)
+        return (*dxs, *dws)
+
+
+def linear3(modules, xs):
+    """(m(x) for m, x in zip(modules, xs)) for three bias-free nn.Linear of equal shape; one node with internal stream concurrency in training on the GPU."""
+    if (OVERLAP_WGRAD and DGRAD_TN and all(m.bias is None for m in modules) and all(x.is_cuda and x.requires_grad for x in xs) and torch.is_grad_enabled()
+            and all(m.weight.requires_grad for m in modules)):
+        return _Linear3TN.apply(*xs, *[m.weight for m in modules])
+    return tuple(linear(m, x) for m, x in zip(modules, xs))
 
 
 def transpose2d(w):
@@ -425,16 +497,25 @@ class _ReluSqLinear(torch.autograd.Function):
         lib = hip_lib.load()
         dy = dy.contiguous()
         dw = None
-        if ctx.needs_input_grad[1]:                          # relu(h)^2 again, only for the weight gradient
-            y = torch.empty_like(h)
-            hip_lib.check(lib.vrwkv_relusq_fwd_bf16(h.numel(), h.data_ptr(), y.data_ptr(), _stream(h)), "vrwkv_relusq_fwd_bf16")
-            dw = _weight_grad(ctx.wparam, dy.reshape(-1, dy.shape[-1]), y.reshape(-1, y.shape[-1]))
-            del y
+        both = OVERLAP_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
+        cur = torch.cuda.current_stream(h.device)
+        side = _side_stream(h.device) if both else cur
+        if ctx.needs_input_grad[1]:                          # relu(h)^2 again, only for the weight gradient (on the side stream beside the input gradient: OVERLAP_WGRAD)
+            if both:
+                side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                y = torch.empty_like(h)
+                hip_lib.check(lib.vrwkv_relusq_fwd_bf16(h.numel(), h.data_ptr(), y.data_ptr(), _stream(h)), "vrwkv_relusq_fwd_bf16")
+                dw = _weight_grad(ctx.wparam, dy.reshape(-1, dy.shape[-1]), y.reshape(-1, y.shape[-1]))
+                del y
         dh = None
         if ctx.needs_input_grad[0]:
             dyy = F.linear(dy, transpose2d(w))               # gradient of relu(h)^2 (the allocator hands it the bytes just freed)
             dh = torch.empty_like(h)
             hip_lib.check(lib.vrwkv_relusq_bwd_bf16(h.numel(), h.data_ptr(), dyy.data_ptr(), dh.data_ptr(), _stream(h)), "vrwkv_relusq_bwd_bf16")
+        if both:
+            cur.wait_stream(side)
+            dw.record_stream(cur)
         return dh, dw
 
 
@@ -843,10 +924,8 @@ def tmix_from_mixed(m, mixed, v_first, recompute_state=False):
     xr, xw, xk, xv, xa, xg = mixed[:6]
     xv_b = mixed[6] if len(mixed) > 6 else xv
     mm = lora_mm if torch.is_grad_enabled() and LORA_WGRAD else torch.matmul     # training: skinny weight-gradient kernel in the backward
-    r = linear(m.receptance, xr)
+    r, k, v = linear3((m.receptance, m.key, m.value), (xr, xk, xv))
     w = decay(mm(torch.tanh(mm(xw, m.w1)), m.w2), m.w0)
-    k = linear(m.key, xk)
-    v = linear(m.value, xv)
     al = mm(mm(xa, m.a1), m.a2)
     g = mm(torch.sigmoid(mm(xg, m.g1)), m.g2)
     if m.layer_id == 0:
