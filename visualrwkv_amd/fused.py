@@ -101,6 +101,7 @@ FLAT_WGRAD = os.environ.get("VRWKV_FLAT_WGRAD", "1") != "0"      # A/B switch: 0
 # dgrad (library GEMM) and wgrad (csrc/wgrad_big.h) of one Linear on two HIP streams, joined before the node returns: both are whole-chip kernels whose LAST
 # round of workgroups is part-filled (C x C at 41 984 rows: 5.125 rounds of 256 x 256 tiles cost 6, profiles/r6h_gemm_tail_probe.jsonl), and a kernel of another
 # stream takes the idle CUs.  The streams never leave the autograd node, so what autograd and the ZeRO-1 hooks see is unchanged.  0 = one after the other.
+# (The same for the skinny LoRA products measured +0.7 % -- two 50 us memory-bound kernels gain less than the two stream joins cost -- and is not done.)
 OVERLAP_WGRAD = os.environ.get("VRWKV_OVERLAP_WGRAD", "1") != "0"
 _SIDE_STREAMS = {}
 
