@@ -42,6 +42,12 @@ FWD_B, BWD_B = 34, 46          # algorithmic bytes per bf16 element at chunk len
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md
 
 
+def _concurrency_keys():
+    """Which groups of library GEMMs ran on more than one HIP stream (True) or one after the other (False): visualrwkv_amd/gemm_tuning.py."""
+    from visualrwkv_amd import gemm_tuning
+    return gemm_tuning.concurrency_report()
+
+
 def build_args(name, ctx_len, n_img_tokens, towers, grad_cp, fused, vit_minibatch=4, image_size=None):
     m = MODELS[name]
     tiny = name == "tiny"
@@ -437,6 +443,7 @@ def main():
                        "grad_cp": a.grad_cp, "fused_elementwise": bool(args.fused), "loss": float(loss.detach()),
                        "micro_bsz": a.micro_bsz, "peak_mem_GB": None if cpu_mode else round(peak_headline, 1),
                        "gemm_kernels": f"TunableOp file, {n_tuned} shapes" if n_tuned else "library default",
+                       "library_gemms_on_two_streams": _concurrency_keys(),
                        "grad_cp_meaning": "0 keep all activations (headline) | 1 = the reference's --grad_cp 1: every block re-computed | 2 = selective recompute",
                        "grad_cp1_reference_recipe_same_run": cp_ref, "grad_cp2_selective_same_run": cp_sel},
             "per_rank": {"tokens_per_step": a.micro_bsz * a.ctx_len, "micro_bsz": a.micro_bsz, "ranks": world,

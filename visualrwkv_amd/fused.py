@@ -13,7 +13,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from . import hip_lib
+from . import gemm_tuning, hip_lib
 from .wkv7 import RUN_CUDA_RWKV7g
 
 
@@ -102,6 +102,10 @@ FLAT_WGRAD = os.environ.get("VRWKV_FLAT_WGRAD", "1") != "0"      # A/B switch: 0
 # round of workgroups is part-filled (C x C at 41 984 rows: 5.125 rounds of 256 x 256 tiles cost 6, profiles/r6h_gemm_tail_probe.jsonl), and a kernel of another
 # stream takes the idle CUs.  The streams never leave the autograd node, so what autograd and the ZeRO-1 hooks see is unchanged.  0 = one after the other.
 # (The same for the skinny LoRA products measured +0.7 % -- two 50 us memory-bound kernels gain less than the two stream joins cost -- and is not done.)
+# SAFETY: the side stream carries only this package's own kernels (wgrad_big, relu^2), never a second LIBRARY GEMM: hipBLASLt's default pick for large
+# shapes is a stream-K kernel whose workgroups spin on each other, and two of those on two streams deadlock the GPU (gemm_tuning's docstring).  Where both
+# sides would be library GEMMs (the r/k/v forward, a weight gradient the library computes) the streams are used only for shapes listed as checked in the
+# loaded tuning file's sidecar (gemm_tuning.concurrent_ok); everything else runs one after the other.
 OVERLAP_WGRAD = os.environ.get("VRWKV_OVERLAP_WGRAD", "1") != "0"
 _SIDE_STREAMS = {}
 
@@ -138,6 +142,18 @@ def wgrad_big(dy2d, x2d, out=None):
     rc = lib.vrwkv_wgrad_big_bf16(M, N, K, dy2d.data_ptr(), x2d.data_ptr(), out.data_ptr(), ws.data_ptr() if ws is not None else 0, _stream(dy2d))
     hip_lib.check(rc, "vrwkv_wgrad_big_bf16")
     return out
+
+
+def _wgrad_beside_dgrad(wp, dy2, x2):
+    """May dW = dy2^T x2 run on the side stream while the library computes the input gradient?  Yes when it is csrc/wgrad_big.h (the same conditions as
+    in _weight_grad), or when this shape's pair of library kernels is listed as checked."""
+    if not (OVERLAP_WGRAD and dy2.is_cuda):
+        return False
+    flat = (FLAT_WGRAD and wp is not None and wp.grad is None and getattr(wp, "_vrwkv_flat_armed", False)
+            and not getattr(wp, "_vrwkv_wgrad_pending", False) and wp._vrwkv_flat_grad[0].dtype == dy2.dtype)
+    if wgrad_big_supported(dy2, x2) and (not flat or wp._vrwkv_flat_grad[1] % 8 == 0):
+        return True
+    return gemm_tuning.concurrent_ok(f"dgrad+wgrad {dy2.shape[0]}x{dy2.shape[1]}x{x2.shape[1]}")
 
 
 def _weight_grad(wp, dy2, x2):
@@ -178,8 +194,10 @@ class _LinearTN(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dx = dw = None
-        if OVERLAP_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and dy.is_cuda:
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and dy.is_cuda:
             dy = dy.contiguous()
+        if (ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
+                and _wgrad_beside_dgrad(ctx.wparam, dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1]))):
             cur, side = torch.cuda.current_stream(dy.device), _side_stream(dy.device)
             side.wait_stream(cur)                                    # dy and x are ready
             with torch.cuda.stream(side):
@@ -204,6 +222,9 @@ class _Linear3TN(torch.autograd.Function):
     def forward(ctx, x0, x1, x2, w0, w1, w2):
         ctx.save_for_backward(x0, x1, x2, w0, w1, w2)
         ctx.wparams = [w if hasattr(w, "_vrwkv_flat_grad") else None for w in (w0, w1, w2)]
+        M = x0.numel() // x0.shape[-1]
+        if not gemm_tuning.concurrent_ok(f"3x tn_{w0.shape[0]}_{M}_{w0.shape[1]}"):       # three library GEMMs at once: checked shapes only (see OVERLAP_WGRAD)
+            return F.linear(x0, w0), F.linear(x1, w1), F.linear(x2, w2)
         cur = torch.cuda.current_stream(x0.device)
         sides = [_side_stream(x0.device, 0), _side_stream(x0.device, 1)]
         outs = [None, None, None]
@@ -221,16 +242,19 @@ class _Linear3TN(torch.autograd.Function):
     def backward(ctx, d0, d1, d2):
         x0, x1, x2, w0, w1, w2 = ctx.saved_tensors
         dys = [d.contiguous() for d in (d0, d1, d2)]
-        cur, side = torch.cuda.current_stream(x0.device), _side_stream(x0.device)
-        side.wait_stream(cur)
-        dws = []
+        jobs = [(wp, dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])) for wp, dy, x in zip(ctx.wparams, dys, (x0, x1, x2))]
+        beside = all(_wgrad_beside_dgrad(*j) for j in jobs)
+        cur = torch.cuda.current_stream(x0.device)
+        side = _side_stream(x0.device) if beside else cur
+        if beside:
+            side.wait_stream(cur)
         with torch.cuda.stream(side):
-            for wp, dy, x in zip(ctx.wparams, dys, (x0, x1, x2)):
-                dws.append(_weight_grad(wp, dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])))
+            dws = [_weight_grad(*j) for j in jobs]
         dxs = [F.linear(dy, transpose2d(w)) for dy, w in zip(dys, (w0, w1, w2))]
-        cur.wait_stream(side)
-        for dw in dws:
-            dw.record_stream(cur)
+        if beside:
+            cur.wait_stream(side)
+            for dw in dws:
+                dw.record_stream(cur)
         return (*dxs, *dws)
 
 
@@ -498,7 +522,8 @@ class _ReluSqLinear(torch.autograd.Function):
         lib = hip_lib.load()
         dy = dy.contiguous()
         dw = None
-        both = OVERLAP_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
+        both = (ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
+                and _wgrad_beside_dgrad(ctx.wparam, dy.reshape(-1, dy.shape[-1]), h.reshape(-1, h.shape[-1])))
         cur = torch.cuda.current_stream(h.device)
         side = _side_stream(h.device) if both else cur
         if ctx.needs_input_grad[1]:                          # relu(h)^2 again, only for the weight gradient (on the side stream beside the input gradient: OVERLAP_WGRAD)

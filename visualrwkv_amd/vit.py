@@ -26,6 +26,7 @@ import torch.nn.functional as F
 
 import os
 
+from . import gemm_tuning
 from .attention import attention, attention_relpos
 
 VIT_STREAMS = os.environ.get("VRWKV_VIT_STREAMS", "1") != "0"      # the towers of SamDinoSigLIPViTBackbone on one HIP stream each
@@ -451,10 +452,13 @@ class SamDinoSigLIPViTBackbone(nn.Module):
     def forward(self, pixel_values: Dict[str, torch.Tensor]) -> torch.Tensor:
         """Concatenated features of the towers (src/vision.py:123-134).  On the device and without autograd (the towers are frozen) the towers run
         CONCURRENTLY, one HIP stream each: a tower's GEMMs have 16 384 rows x 1 024-1 152 columns = 320 tiles of 256 x 256 for 256 CUs, i.e. a full
-        round and a quarter-filled one, and the other tower's kernels take the idle CUs (VRWKV_VIT_STREAMS=0: one after the other)."""
+        round and a quarter-filled one, and the other tower's kernels take the idle CUs (VRWKV_VIT_STREAMS=0: one after the other).  Library GEMMs of
+        two streams at once are only safe with kernels that were checked side by side (gemm_tuning's docstring: two stream-K kernels deadlock), so
+        this needs the tower configuration's key in the loaded tuning file's sidecar; otherwise the towers run one after the other."""
         names = [n for n in ("dino", "siglip", "sam") if n in self.towers]
         x0 = pixel_values[names[0]]
-        if VIT_STREAMS and len(names) > 1 and x0.is_cuda and not torch.is_grad_enabled():
+        if (VIT_STREAMS and len(names) > 1 and x0.is_cuda and not torch.is_grad_enabled()
+                and gemm_tuning.concurrent_ok("vit " + " ".join(f"{n}:{'x'.join(str(d) for d in pixel_values[n].shape)}" for n in names))):
             cur = torch.cuda.current_stream(x0.device)
             if self._streams is None or self._streams[0].device != x0.device:
                 self._streams = [torch.cuda.Stream(device=x0.device) for _ in names[1:]]
