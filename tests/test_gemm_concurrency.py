@@ -9,7 +9,7 @@ from visualrwkv_amd import gemm_tuning
 
 
 def test_nothing_is_concurrent_without_a_loaded_tuning_file():
-    assert gemm_tuning._CONCURRENT_OK == frozenset() or torch.cuda.is_available()
+    assert gemm_tuning._CONCURRENT_OK == {} or torch.cuda.is_available()
     assert not gemm_tuning.concurrent_ok("3x tn_768_67200_768")
     assert not gemm_tuning.concurrent_ok()
     assert gemm_tuning.concurrency_report()["3x tn_768_67200_768"] is False
@@ -18,9 +18,18 @@ def test_nothing_is_concurrent_without_a_loaded_tuning_file():
 def test_sidecar_lists_keys_and_ignores_comments(tmp_path):
     f = tmp_path / "t.csv"
     f.write_text("Validator,PT_VERSION,0\n")
-    (tmp_path / "t.csv.concurrent").write_text("# a comment\n3x tn_8_16_8\n\nvit a:1x3x4x4 b:1x3x4x4\n")
-    assert gemm_tuning._read_sidecar(str(f)) == frozenset({"3x tn_8_16_8", "vit a:1x3x4x4 b:1x3x4x4"})
-    assert gemm_tuning._read_sidecar(str(tmp_path / "missing.csv")) == frozenset()
+    (tmp_path / "t.csv.concurrent").write_text("# a comment\n3x tn_8_16_8\n\nvit a:1x3x4x4 b:1x3x4x4 !one-rank\n")
+    assert gemm_tuning._read_sidecar(str(f)) == {"3x tn_8_16_8": False, "vit a:1x3x4x4 b:1x3x4x4": True}
+    assert gemm_tuning._read_sidecar(str(tmp_path / "missing.csv")) == {}
+
+
+def test_keys_marked_one_rank_are_withdrawn_when_a_multi_rank_engine_exists(monkeypatch):
+    monkeypatch.setattr(gemm_tuning, "_CONCURRENT_OK", {"3x tn_8_16_8": False, "vit a b": True})
+    monkeypatch.setattr(gemm_tuning, "_COLLECTIVES", False)
+    assert gemm_tuning.concurrent_ok("3x tn_8_16_8") and gemm_tuning.concurrent_ok("vit a b")
+    gemm_tuning.note_collectives(True)
+    assert gemm_tuning.concurrent_ok("3x tn_8_16_8") and not gemm_tuning.concurrent_ok("vit a b")
+    assert not gemm_tuning.concurrent_ok("3x tn_8_16_8", "vit a b")
 
 
 def test_shipped_sidecar_names_only_shapes_of_the_shipped_tuning_file():
@@ -80,4 +89,4 @@ def test_listed_shape_runs_on_three_streams_with_the_shipped_file():
         torch.cuda.synchronize()
     finally:
         tn.enable(False)
-        gemm_tuning._CONCURRENT_OK = frozenset()
+        gemm_tuning._CONCURRENT_OK = {}

@@ -72,6 +72,9 @@ class Zero1Engine:
         # force_collectives: run the full hook / side-stream / reduce-scatter / all-gather path even with one
         # rank (used to exercise the RCCL code path on a single-GPU box)
         self.collective = self.world > 1 or (force_collectives and dist.is_initialized())
+        if self.world > 1:
+            from . import gemm_tuning
+            gemm_tuning.note_collectives(True)      # stream-K library GEMMs on two streams beside RCCL kernels: never validated, so not done (gemm_tuning.py)
         params = [p for p in model.parameters() if p.requires_grad]
         assert params, "nothing to train"
         self.device = params[0].device

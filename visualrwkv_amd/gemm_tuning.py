@@ -27,16 +27,25 @@ import os
 import tempfile
 
 DEFAULT_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "tunableop_gfx950_1b5_mb16.csv")
-_CONCURRENT_OK: frozenset = frozenset()
+_CONCURRENT_OK: dict = {}          # key -> True when granted only without collectives on another stream (a trailing " !one-rank" in the sidecar)
+_COLLECTIVES = False               # a multi-rank ZeRO-1 engine drives RCCL kernels on its own stream (dp.Zero1Engine sets this)
 _ASKED: dict = {}
+
+
+def note_collectives(active: bool = True) -> None:
+    """dp.Zero1Engine with more than one rank: keys marked `!one-rank` (their kernels are stream-K grids that need most of the chip's resident slots;
+    beside RCCL kernels that is not validated -- there is no multi-GPU box in this project's pool) are no longer granted."""
+    global _COLLECTIVES
+    _COLLECTIVES = bool(active)
 
 
 def concurrent_ok(*keys: str) -> bool:
     """True when every key is listed as checked in the loaded tuning file's `.concurrent` sidecar (see the module docstring)."""
-    ok = bool(keys) and all(k in _CONCURRENT_OK for k in keys)
+    def granted(k):
+        return k in _CONCURRENT_OK and not (_CONCURRENT_OK[k] and _COLLECTIVES)
     for k in keys:
-        _ASKED[k] = k in _CONCURRENT_OK
-    return ok
+        _ASKED[k] = granted(k)
+    return bool(keys) and all(granted(k) for k in keys)
 
 
 def concurrency_report() -> dict:
@@ -44,12 +53,13 @@ def concurrency_report() -> dict:
     return dict(_ASKED)
 
 
-def _read_sidecar(path: str) -> frozenset:
+def _read_sidecar(path: str) -> dict:
     try:
         with open(path + ".concurrent") as f:
-            return frozenset(ln.strip() for ln in f if ln.strip() and not ln.startswith("#"))
+            lines = [ln.strip() for ln in f if ln.strip() and not ln.startswith("#")]
     except OSError:
-        return frozenset()
+        return {}
+    return {ln.removesuffix("!one-rank").strip(): ln.endswith("!one-rank") for ln in lines}
 
 
 def enable_tuned_gemms(path: str | None = None) -> int:
@@ -57,7 +67,7 @@ def enable_tuned_gemms(path: str | None = None) -> int:
     Returns the number of shapes loaded (0: file missing or rejected by the validators; defaults stay in use)."""
     import torch.cuda.tunable as tn
     global _CONCURRENT_OK
-    _CONCURRENT_OK = frozenset()
+    _CONCURRENT_OK = {}
     path = path or DEFAULT_FILE
     if not os.path.exists(path):
         return 0
@@ -69,5 +79,5 @@ def enable_tuned_gemms(path: str | None = None) -> int:
         tn.enable(False)
         return 0
     # VRWKV_CONCURRENT_TRY="key;key": extra keys for the run that checks them on the hardware before they are listed (a wrong one can hang the GPU)
-    _CONCURRENT_OK = _read_sidecar(path) | frozenset(k.strip() for k in os.environ.get("VRWKV_CONCURRENT_TRY", "").split(";") if k.strip())
+    _CONCURRENT_OK = {**_read_sidecar(path), **{k.strip(): False for k in os.environ.get("VRWKV_CONCURRENT_TRY", "").split(";") if k.strip()}}
     return len(tn.get_results())
