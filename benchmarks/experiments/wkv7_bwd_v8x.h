@@ -54,6 +54,13 @@ template <int IMM, int CPOL = 0> DEVFN void lds_dma16_lean_cp(const void* unifor
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
                  :: "v"(lane_byte_off), "s"(uniform_base), "s"(lds_dst_uniform), "n"(IMM) : "memory", "m0");
 }
+// one dword per lane into a scratch line of LDS: a request whose only purpose is to bring the lane's 128-byte line into L2 (OPT & 65536)
+DEVFN void lds_dma4_touch(const void* uniform_base, unsigned lane_byte_off, unsigned lds_dst_uniform) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
+                 :: "v"(lane_byte_off), "s"(uniform_base), "s"(lds_dst_uniform) : "memory", "m0");
+}
+#else
+DEVFN void lds_dma4_touch(const void*, unsigned, unsigned) {}
 #endif
 #include <wkv7_bwd_rows.h>     // ChunkImg7, RawP, DmaLane, dma_lane, prep7, dscores-style helpers; through it v6 / v5 building blocks
 
@@ -149,6 +156,7 @@ struct LdsV8 {
         float x2r[3][IMG];           // JTAIL: log2 c_t [t][j] of chunk c in slot c % 3 (P waves -> the J waves' tail two steps later)
     };
     float glast[2][N];               // sum_i dS_L[i][j] S_L[i][j] at the chunk's last token, by chunk parity
+    unsigned touch[2][64];           // OPT & 65536: landing scratch of the L2 touches (never read)
     unsigned flag[8];                // 0: M_qa, M_qk, M_zk written (3 per step)  1: dM written (3)  2: T written (1)  3: J operands split (4)
                                      // 4: tail has read `res` (4)  5: P waves hold their staging pieces (4)      (flag 1: four I waves since the score-gradient pieces were re-dealt)
 };
@@ -441,6 +449,11 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
                     n_ps += 4u;
                     if (w > 0) lds_flag_wait(&lds.flag[5], n_ps);      // ... all four P waves hold their pieces: the staging bytes are free
                 }
+                // OPT & 65536: S0 of the NEXT step's chunk is touched now (one dword of each of its 128 lines, waves 1 and 2: one request each), so that
+                // the 16 KB requested after flag 3 of the next step come from L2 instead of HBM.  First requests of the step: the counted wait at its
+                // end is unchanged.
+                if ((OPT & 65536) && FULL && (w == 1 || w == 2) && cd >= 2)
+                    lds_dma4_touch(sbase + (size_t)(cd - 2) * N * N, (unsigned)(lane + 64 * (w - 1)) * 128u, lds_addr_u32(lds.touch[w - 1]));
                 // waves 1-3 request the rows of the next chunk (6 instructions each); wave 0 has the T chain instead
                 if (FULL) {
                     const unsigned cb16 = (unsigned)((head_base + (size_t)(cp - 1) * L * ts) * 2u);
