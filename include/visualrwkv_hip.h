@@ -333,6 +333,10 @@ int vrwkv_adaptive_pool_bf16(int B, int side_in, int side_out, int D, const void
  * and, when dx is not NULL, dx = dout s. */
 int vrwkv_gate_fwd_bf16(long n, const void* x, const void* g, void* out, void* stream);
 int vrwkv_gate_bwd_bf16(long n, const void* x, const void* g, const void* dout, void* dg, void* dx, void* stream);
+/* nn.GELU of the frozen towers' MLPs (timm `Mlp` run by src/vision.py:123-134: DINOv2 exact, SigLIP `gelu_tanh`; src/sam.py MLPBlock exact) over n bf16
+ * elements (n % 8 == 0), y may be x: tanh_approx != 0 = 0.5 x (1 + tanh(sqrt(2/pi)(x + 0.044715 x^3))); 0 = 0.5 x (1 + erf(x / sqrt 2)), erfc to 1.2e-7
+ * relative (fp32 arithmetic, one rounding to bf16). */
+int vrwkv_gelu_bf16(long n, const void* x, void* y, int tanh_approx, void* stream);
 /* ln_v of the projector fused with the masked scatter of preparing_embedding: out[row_index[n]] = LayerNorm(x[n]) for the
  * ntok projected image tokens, written into the (rows, C) token-embedding tensor `out`; row_index: device int64, distinct; a negative entry drops that
  * feature row (fewer placeholders than features: the reference truncates, src/model.py:487-491).  mean /

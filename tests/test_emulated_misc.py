@@ -111,6 +111,28 @@ def test_adaptive_pool_and_gate(emu_lib):
     assert rel(dx, do.float() * s) < 3e-3 and rel(dg, do.float() * a.float() * s * (1 - s)) < 4e-3
 
 
+def test_gelu_exact_and_tanh_against_torch(emu_lib):
+    """csrc/visual_ops.hip gelu_kernel: the towers' nn.GELU (timm Mlp via src/vision.py:123-134; src/sam.py MLPBlock), both approximations, in place.
+    Tolerance: the correctly rounded bf16 of the fp64 value, except at rounding ties."""
+    g = torch.Generator().manual_seed(6)
+    n = 4096
+    x = (torch.randn(n, generator=g) * 3).bfloat16()
+    x[:16] = torch.tensor([0.0, -0.0, 1e-3, -1e-3, 0.5, -0.5, 1, -1, 2, -2, 4, -4, 8, -8, 30, -30]).bfloat16()
+    for tanh in (0, 1):
+        y = x.clone()
+        call(emu_lib, "vrwkv_gelu_bf16", [L, VP, VP, I, VP], n, P(y), P(y), tanh, None)
+        want64 = F.gelu(x.double(), approximate="tanh" if tanh else "none")     # fp64: torch's fp32 kernel forms 1 + erf(.) and loses the negative tail to cancellation
+        want = want64.bfloat16()
+        assert torch.isfinite(y.float()).all()
+        assert ((y.double() - want64).abs() <= want64.abs() * 2.0 ** -8 * 1.01 + 1e-12).all(), "more than half a bf16 step from the exact value"
+        big = want64.abs() > 1e-10                           # below, even the fp64 reference has lost 1 + erf(.) to cancellation
+        assert (y != want)[big].float().mean() < 0.002       # rounding ties only
+        t32 = F.gelu(x.float(), approximate="tanh" if tanh else "none")          # and torch's own fp32 kernel agrees to its accuracy
+        assert ((y.float() - t32).abs() <= (t32.abs() * 2.0 ** -7).clamp_min(1e-6)).all()
+    f = emu_lib.vrwkv_gelu_bf16
+    assert f(12, P(y), P(y), 0, None) == -2 and f(0, P(y), P(y), 0, None) == -1 and f(8, None, P(y), 0, None) == -1
+
+
 def test_wkv7_single_token_step_against_the_recurrence(emu_lib):
     """csrc/wkv7_step.hip: five tokens stepped one by one through the carried (B,H,64,64) state against the reference's per-token
     recurrence (RWKV-v7_simple.py:20-32 as oracle.wkv7_oracle.wkv7_naive states it) -- y to bf16 rounding, the state to fp32."""

@@ -272,8 +272,9 @@ def test_timm_style_towers_on_the_gpu_against_transformers(tower, monkeypatch):
     with torch.no_grad():
         hs = hf(pixel_values=x, output_hidden_states=True).hidden_states[2]
         ref = hs if tower == "siglip" else hs[:, 5:]
-    calls = {"pe": 0, "fa": 0}
-    pe, fa = fused.patch_embed, hip_attention.flash_forward
+    calls = {"pe": 0, "fa": 0, "gelu": 0}
+    pe, fa, ge = fused.patch_embed, hip_attention.flash_forward, fused.gelu_
+    monkeypatch.setattr(fused, "gelu_", lambda *a, **k: (calls.__setitem__("gelu", calls["gelu"] + 1), ge(*a, **k))[1])
     monkeypatch.setattr(fused, "patch_embed", lambda *a, **k: (calls.__setitem__("pe", calls["pe"] + 1), pe(*a, **k))[1])
     monkeypatch.setattr(hip_attention, "flash_forward", lambda *a, **k: (calls.__setitem__("fa", calls["fa"] + 1), fa(*a, **k))[1])
     m = mine.cuda().bfloat16()
@@ -281,6 +282,28 @@ def test_timm_style_towers_on_the_gpu_against_transformers(tower, monkeypatch):
         p_.requires_grad_(False)
     with torch.no_grad():
         got = m(x.cuda().bfloat16())
-    assert calls["pe"] == 1 and calls["fa"] == 2                     # the HIP kernels are what ran (2 blocks up to depth-2)
+    assert calls["pe"] == 1 and calls["fa"] == 2 and calls["gelu"] == 2      # the HIP kernels are what ran (2 blocks up to depth-2)
     assert got.shape == ref.shape
     assert rel_rms(got.float().cpu(), ref) < 2e-2                    # bf16 weights and activations vs fp32
+
+
+@pytest.mark.parametrize("tanh", [False, True])
+def test_gelu_kernel_against_fp64(tanh):
+    """csrc/visual_ops.hip: nn.GELU of the towers' MLPs (timm Mlp via src/vision.py:123-134; src/sam.py MLPBlock), in place, at a tower's real
+    size (16 384 x 4 304): the correctly rounded bf16 of the fp64 value except at rounding ties, and within torch's own fp32 kernel's accuracy."""
+    import torch.nn.functional as F
+    from visualrwkv_amd import fused
+    torch.manual_seed(5)
+    x = (torch.randn(16384, 4304, device="cuda") * 2.5).bfloat16()
+    x.view(-1)[:8] = torch.tensor([0.0, -0.0, 1e-3, -4.0, 4.0, -9.0, 30.0, -30.0], device="cuda").bfloat16()
+    y = fused.gelu_(x.clone(), tanh)
+    approx = "tanh" if tanh else "none"
+    xs, ys = x[:512].double(), y[:512]                                       # fp64 on a slice (the whole tensor in fp64 is 560 MB per temporary)
+    want64 = F.gelu(xs, approximate=approx)
+    assert ((ys.double() - want64).abs() <= want64.abs() * 2.0 ** -8 * 1.01 + 1e-12).all()
+    big = want64.abs() > 1e-10
+    assert (ys != want64.bfloat16())[big].float().mean() < 0.002
+    t32 = F.gelu(x.float(), approximate=approx)
+    assert ((y.float() - t32).abs() <= (t32.abs() * 2.0 ** -7).clamp_min(1e-6)).all()
+    with pytest.raises(ValueError):
+        fused.gelu_(x[:, :100], tanh)                                        # not contiguous

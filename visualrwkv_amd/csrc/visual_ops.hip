@@ -78,6 +78,36 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(long nvec, const uint16_t
     }
 }
 
+// nn.GELU of the towers' MLPs (timm Mlp via src/vision.py:123-134; src/sam.py MLPBlock), one 16-byte vector per thread (the launch shape of relusq_*).
+// TANH (SigLIP's gelu_tanh): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3), written as x * sigmoid(2u): one v_exp and one v_rcp.
+// exact (DINOv2, SAM): 0.5 x (1 + erf(x / sqrt 2)) with erfc(|z|) = t exp(-z^2 + P9(t)), t = 1 / (1 + |z| / 2) (the Chebyshev fit of Numerical Recipes 6.2:
+// fractional error < 1.2e-7 for every z, so the negative tail keeps its relative accuracy) -- bf16 keeps 8 bits; PyTorch's kernel (ocml erff, ~45 VALU
+// operations per element) is VALU-bound at 2.3 TB/s on this GEMM output.
+template <bool TANH>
+__global__ __launch_bounds__(256) void gelu_kernel(long nvec, const uint16_t* __restrict__ x, uint16_t* __restrict__ y) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvec) return;
+    float f[8], o[8];
+    unpack8f(reinterpret_cast<const uint4*>(x)[i], f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float v = f[e];
+        if (TANH) {
+            const float u2 = 1.5957691216057308f * v * fmaf(0.044715f * v, v, 1.f);      // 2u
+            o[e] = v * fast_rcp(1.f + fast_exp(-u2));
+        } else {
+            const float z = fabsf(v) * 0.7071067811865476f;
+            const float t = fast_rcp(fmaf(0.5f, z, 1.f));
+            float pl = fmaf(t, 0.17087277f, -0.82215223f);
+            pl = fmaf(t, pl, 1.48851587f); pl = fmaf(t, pl, -1.13520398f); pl = fmaf(t, pl, 0.27886807f); pl = fmaf(t, pl, -0.18628806f);
+            pl = fmaf(t, pl, 0.09678418f); pl = fmaf(t, pl, 0.37409196f); pl = fmaf(t, pl, 1.00002368f); pl = fmaf(t, pl, -1.26551223f);
+            const float q = t * fast_exp(fmaf(-z, z, pl));                                 // erfc(|z|)
+            o[e] = 0.5f * v * (v >= 0.f ? 2.f - q : q);
+        }
+    }
+    reinterpret_cast<uint4*>(y)[i] = pack8f(o);
+}
+
 int grid_for(long nvec) {
     long b = (nvec + 255) / 256;
     return (int)(b < 1 ? 1 : b > 2048 ? 2048 : b);
@@ -110,6 +140,17 @@ int vrwkv_gate_bwd_bf16(long n, const void* x, const void* g, const void* dout, 
     if (n % 8 != 0) return VRWKV_ESHAPE;
     hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for(n >> 3)), dim3(256), 0, (hipStream_t)stream, n >> 3, (const uint16_t*)x,
                        (const uint16_t*)g, (const uint16_t*)dout, (uint16_t*)dg, (uint16_t*)dx);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? VRWKV_OK : (int)e;
+}
+
+int vrwkv_gelu_bf16(long n, const void* x, void* y, int tanh_approx, void* stream) {
+    if (n <= 0 || !x || !y) return VRWKV_EINVAL;
+    if (n % 8 != 0) return VRWKV_ESHAPE;
+    const long nvec = n / 8, blocks = (nvec + 255) / 256;
+    if (blocks > 0x7fffffffL) return VRWKV_ESHAPE;
+    if (tanh_approx) hipLaunchKernelGGL(gelu_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, nvec, (const uint16_t*)x, (uint16_t*)y);
+    else hipLaunchKernelGGL(gelu_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, nvec, (const uint16_t*)x, (uint16_t*)y);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? VRWKV_OK : (int)e;
 }

@@ -1082,6 +1082,16 @@ def gate(x, g):
     return _Gate.apply(x, g)
 
 
+def gelu_(x, tanh_approx=False):
+    """nn.GELU of the frozen towers' MLPs, IN PLACE on a contiguous bf16 device tensor without autograd (timm Mlp through src/vision.py:123-134,
+    src/sam.py MLPBlock): csrc/visual_ops.hip, 16 VALU operations per element where the eager erf kernel is VALU-bound at 2.3 TB/s."""
+    _chk(x)
+    if x.requires_grad or x.numel() % 8 != 0 or not x.is_contiguous():
+        raise ValueError("gelu_: contiguous, no autograd, a multiple of 8 elements")
+    hip_lib.check(hip_lib.load().vrwkv_gelu_bf16(x.numel(), x.data_ptr(), x.data_ptr(), 1 if tanh_approx else 0, _stream(x)), "vrwkv_gelu_bf16")
+    return x
+
+
 class _LnScatter(torch.autograd.Function):
     """embeds[row_index[n]] = LayerNorm(y[n]): ln_v of the projector fused with the masked scatter into the token
     embeddings (model.py:338 + :485-493).  `embeds` (rows, C) is modified in place and returned."""

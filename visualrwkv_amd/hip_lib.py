@@ -73,6 +73,7 @@ PROTOTYPES = {
     "vrwkv_patch_embed_kp": (_c_int, [_c_int]),
     "vrwkv_adamw_step_bf16": (_c_int, [ctypes.c_long] + [_c_void_p] * 5 + [ctypes.c_float] * 5 + [_c_int, ctypes.c_float, ctypes.c_long, ctypes.c_long, _c_void_p]),
     "vrwkv_adaptive_pool_bf16": (_c_int, [_c_int] * 4 + [_c_void_p] * 3),
+    "vrwkv_gelu_bf16": (_c_int, [_c_long, _c_void_p, _c_void_p, _c_int, _c_void_p]),
     "vrwkv_gate_fwd_bf16": (_c_int, [_c_long] + [_c_void_p] * 4),
     "vrwkv_gate_bwd_bf16": (_c_int, [_c_long] + [_c_void_p] * 6),
     "vrwkv_ln_scatter_fwd_bf16": (_c_int, [_c_long, _c_int, _c_float] + [_c_void_p] * 8),

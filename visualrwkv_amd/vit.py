@@ -88,12 +88,14 @@ def _tower_fused(x, dim):
 
 
 def _mlp_infer(mlp, h):
-    """fc2(gelu(fc1(h))); for the tanh-approximated GELU (SigLIP) bias + activation ride in the library GEMM's epilogue."""
-    if mlp.approx == "tanh" and mlp.fc1.bias is not None:
-        shp = h.shape
-        y = torch._addmm_activation(mlp.fc1.bias, h.reshape(-1, shp[-1]), mlp.fc1.weight.t(), use_gelu=True)
-        return mlp.fc2(y).view(*shp[:-1], -1)
-    return mlp(h)
+    """fc2(gelu(fc1(h))) of a frozen tower on the device: the bias rides in the library GEMM's epilogue, the activation is one in-place streaming kernel
+    (fused.gelu_).  (torch._addmm_activation(use_gelu=True) does not fuse on this ROCm build: it launched the eager GELU kernel -- 118 us per call,
+    VALU-bound on erf / tanh -- 49 times per step, profiles/r6y_step_kernel_stats.csv.)"""
+    from . import fused
+    y = mlp.fc1(h)
+    if y.numel() % 8 == 0 and y.is_contiguous():
+        return mlp.fc2(fused.gelu_(y, mlp.approx == "tanh"))
+    return mlp.fc2(F.gelu(y, approximate=mlp.approx))
 
 
 def _timm_blocks_infer(blocks, x, last):
@@ -206,7 +208,11 @@ class _SamMlp(nn.Module):
         self.lin2 = nn.Linear(hidden, dim)
 
     def forward(self, x):
-        return self.lin2(F.gelu(self.lin1(x)))
+        y = self.lin1(x)
+        if _tower_fused(y, y.shape[-1]) and y.is_contiguous():      # frozen tower on the device: in-place streaming GELU (fused.gelu_)
+            from . import fused
+            return self.lin2(fused.gelu_(y))
+        return self.lin2(F.gelu(y))
 
 
 class _SamAttention(nn.Module):
