@@ -52,6 +52,25 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         raise AssertionError("expected HipLibraryError")
 
 
+def test_library_older_than_its_sources_is_rebuilt_or_refused(monkeypatch):
+    """A library built from other sources than the ones beside it must not be used silently (round 6: a GPU run measured the previous build of a
+    kernel): with a toolchain it is rebuilt, without one loading fails."""
+    import pytest
+    from visualrwkv_amd import build, hip_lib as hl
+    monkeypatch.delenv("VRWKV_HIP_LIB", raising=False)
+    monkeypatch.setattr(hl, "_lib", None)
+    monkeypatch.setattr(build, "_stale", lambda: True)
+    monkeypatch.setattr(build, "hipcc", lambda: (_ for _ in ()).throw(RuntimeError("hipcc not found")))
+    with pytest.raises(hl.HipLibraryError, match="other sources"):
+        hl.load()
+    called = []
+    monkeypatch.setattr(build, "hipcc", lambda: "/opt/rocm/bin/hipcc")
+    monkeypatch.setattr(build, "build", lambda *a, **k: called.append(1))
+    with pytest.warns(RuntimeWarning, match="older than its sources"):
+        hl.load()
+    assert called == [1]
+
+
 def test_op_has_a_cpu_key_and_validates_its_arguments():
     """the op is registered for the CPU key too (BASELINE config 1); wrong dtypes / shapes are errors."""
     import pytest

@@ -110,6 +110,19 @@ def load() -> ctypes.CDLL:
             f"{path} is missing. Build it with `python -m visualrwkv_amd.build` "
             "(hipcc --offload-arch=gfx950); the GPU operators have no PyTorch fallback (CPU tensors go through the op's CPU key: "
             "libvisualrwkv_host.so, hip_lib.load_host()).")
+    if "VRWKV_HIP_LIB" not in os.environ:
+        # A library older than its sources computes what the sources USED to say (round 6: a GPU run against the previous build of a kernel that had just
+        # been changed).  The content hash recorded beside the library travels with it; on a mismatch rebuild (incremental, locked) or refuse.
+        from . import build as _build
+        if _build._stale():
+            import warnings
+            try:
+                _build.hipcc()
+            except RuntimeError as e:
+                raise HipLibraryError(f"{path} was built from other sources than the ones in {_build.CSRC} and there is no hipcc to rebuild it: "
+                                      "run `python -m visualrwkv_amd.build` where the toolchain is") from e
+            warnings.warn(f"{path} is older than its sources: rebuilding it (python -m visualrwkv_amd.build)", RuntimeWarning, stacklevel=2)
+            _build.build()
     lib = ctypes.CDLL(path)
     for name, (res, args) in PROTOTYPES.items():
         try:

@@ -40,6 +40,8 @@ class _Mlp(nn.Module):
         self.approx = "tanh" if act == "gelu_tanh" else "none"
 
     def forward(self, x):
+        if x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled():
+            return _mlp_infer(self, x)
         return self.fc2(F.gelu(self.fc1(x), approximate=self.approx))
 
 
