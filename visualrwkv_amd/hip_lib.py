@@ -114,7 +114,7 @@ def load() -> ctypes.CDLL:
         # A library older than its sources computes what the sources USED to say (round 6: a GPU run against the previous build of a kernel that had just
         # been changed).  The content hash recorded beside the library travels with it; on a mismatch rebuild (incremental, locked) or refuse.
         from . import build as _build
-        if _build._stale():
+        if os.path.exists(_build.HASH_PATH) and _build._stale():      # no recorded hash (the file did not travel): mtimes of a copied tree say nothing, load as is
             import warnings
             try:
                 _build.hipcc()
