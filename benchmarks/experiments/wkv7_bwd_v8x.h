@@ -59,8 +59,10 @@ DEVFN void lds_dma4_touch(const void* uniform_base, unsigned lane_byte_off, unsi
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
                  :: "v"(lane_byte_off), "s"(uniform_base), "s"(lds_dst_uniform) : "memory", "m0");
 }
+DEVFN void sleep_640_cycles() { __builtin_amdgcn_s_sleep(10); }
 #else
 DEVFN void lds_dma4_touch(const void*, unsigned, unsigned) {}
+DEVFN void sleep_640_cycles() {}
 #endif
 #include <wkv7_bwd_rows.h>     // ChunkImg7, RawP, DmaLane, dma_lane, prep7, dscores-style helpers; through it v6 / v5 building blocks
 
@@ -412,6 +414,9 @@ __global__ __launch_bounds__(768) void bwd_kernel_v8(BwdArgs p) {
     WKV_STAMP_DECL
     const unsigned long long rt0_ = PROF ? realtime64_() : 0ull;
 
+    if (OPT & 131072) {                                 // stagger the workgroups: (bh & 7) eighths of a step (~0.33 us each) before anything is requested
+        for (unsigned i = 0; i < (bh & 7u); ++i) sleep_640_cycles();
+    }
     if (tid < 8) lds.flag[tid] = 0u;
     if (role == 2 && !(SKIP & 1)) {                     // rows of the last chunk: staging + its V / dY slot
         const DmaLane dl = dma_lane(lane, ts);

@@ -31,7 +31,7 @@ inline int launch(int var, dim3 grid, hipStream_t st, const wkv7::BwdArgs& p) {
 #define VRWKV_OPT_CASE(v, o) case v: kern = &wkv7v8x::bwd_kernel_v8<false, VRWKV_V8_PI, VRWKV_V8_PJ, VRWKV_V8_PP, 0, true, VRWKV_V8_PP, true, false, o>; break;
         VRWKV_OPT_CASE(20, 0) VRWKV_OPT_CASE(21, 1) VRWKV_OPT_CASE(22, 2) VRWKV_OPT_CASE(23, 3) VRWKV_OPT_CASE(24, 64) VRWKV_OPT_CASE(25, 128) VRWKV_OPT_CASE(26, 192) VRWKV_OPT_CASE(27, 4) VRWKV_OPT_CASE(28, 20) VRWKV_OPT_CASE(29, 4 + 64)
         // cache policy of the requests (rows: bits 8-9, S0: bits 10-11; 1 nt, 2 sc1, 3 sc0 sc1 nt) and non-temporal tail stores (4096)
-        VRWKV_OPT_CASE(30, 256) VRWKV_OPT_CASE(31, 1024) VRWKV_OPT_CASE(32, 1280) VRWKV_OPT_CASE(33, 2048) VRWKV_OPT_CASE(34, 3072) VRWKV_OPT_CASE(35, 4096) VRWKV_OPT_CASE(36, 4096 + 1280) VRWKV_OPT_CASE(37, 512 + 2048) VRWKV_OPT_CASE(38, 8192) VRWKV_OPT_CASE(39, 16384) VRWKV_OPT_CASE(47, 32768) VRWKV_OPT_CASE(48, 16384 + 32768) VRWKV_OPT_CASE(49, 16384 + 32768 + 3 + 256) VRWKV_OPT_CASE(50, 65536) VRWKV_OPT_CASE(51, 65536 + 3)     /* 38: full-row tail stores through the `res` slots */
+        VRWKV_OPT_CASE(30, 256) VRWKV_OPT_CASE(31, 1024) VRWKV_OPT_CASE(32, 1280) VRWKV_OPT_CASE(33, 2048) VRWKV_OPT_CASE(34, 3072) VRWKV_OPT_CASE(35, 4096) VRWKV_OPT_CASE(36, 4096 + 1280) VRWKV_OPT_CASE(37, 512 + 2048) VRWKV_OPT_CASE(38, 8192) VRWKV_OPT_CASE(39, 16384) VRWKV_OPT_CASE(47, 32768) VRWKV_OPT_CASE(48, 16384 + 32768) VRWKV_OPT_CASE(49, 16384 + 32768 + 3 + 256) VRWKV_OPT_CASE(50, 65536) VRWKV_OPT_CASE(51, 65536 + 3) VRWKV_OPT_CASE(52, 131072)     /* 38: full-row tail stores through the `res` slots */
 #undef VRWKV_OPT_CASE
         // static wave priorities of the three roles (I, J, P; the product: 0, 0, 1) on variant 9
 #define VRWKV_PRIO_CASE(v, pi, pj, pp) case v: kern = &wkv7v8x::bwd_kernel_v8<false, pi, pj, pp, 0, true, pp, true, false, 0>; break;
