@@ -68,8 +68,9 @@ def _stale() -> bool:
 # pairs and cannot take DPP operands (every scan step becomes v_mov_dpp + v_pk_add).  Same-box A/B, alternating processes:
 # forward -1..2 %, backward (v5, v6) -1..2 %.
 # tmix_fused / ln_fused / fused_ops (the streaming row kernels and AdamW): the machine scheduler's max-ILP strategy issues the next token's loads earlier in
-# the token loops -- two boxes: adamw -7 %, ln_mix1_bwd -5 / -10 %, kva_bwd -3 %, add_ln_bwd -4 %, the rest within +-2 %; the step -1.2 ms in three same-box
-# alternations; attention unchanged and the WKV7 kernels +2.5 % (not applied there) -- profiles/r6o_eltwise_micro_max_ilp.json, r6n_wkv7_ab_build_flags.jsonl.
+# the token loops -- three boxes: adamw -2 / -7 / -7 %, kva_fwd and mix6_fwd -3 % on one, ln_mix1_bwd 0 / -5 / -10 %, kva_bwd -1 / -3 / -3 %, the rest within
+# +-2 %; the step -1.2 ms in three same-box alternations; `max-memory-clause` = no change; attention unchanged and the WKV7 kernels +2.5 % under max-ilp (not
+# applied there) -- profiles/r6o_eltwise_micro_max_ilp.json, r6n_wkv7_ab_build_flags.jsonl.
 # Same instructions in another order: results are bit-identical.
 _ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 EXTRA_FLAGS = {"attention.hip": ["-fno-honor-nans"], "wkv7_capi.hip": ["-fno-slp-vectorize"], "wkv7_profile.hip": ["-fno-slp-vectorize"],
